@@ -1,0 +1,1304 @@
+/* peaq_oracle.c -- CPU oracle for the per-frame PEAQ path.  TEST INFRASTRUCTURE.
+ *
+ * See peaq_oracle.h for what this is, who may use it and how it is pinned to
+ * the reference.  Citations are file:line under /root/reference/src.
+ *
+ * The reference's third-party arithmetic that is not in /root/reference is
+ * GstFFTF64 (kissfft, gst-plugins-base; version unpinned by the reference,
+ * configure.ac:26-27).  It is a plain unnormalised real DFT, restated here as
+ * orc_fft(); the reference's own known answers for it (testpeaq.c:680-705)
+ * are part of the golden checks.
+ */
+#include "peaq_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define FS 48000.
+#define MAXF(a,b) ((a) > (b) ? (a) : (b))
+#define MINF(a,b) ((a) < (b) ? (a) : (b))
+
+/* ======================================================================== */
+/* DFT                                                                        */
+/* ======================================================================== */
+
+void
+orc_fft (double *re, double *im, int n, int sign)
+{
+  int i, j, len;
+  /* bit reversal */
+  for (i = 1, j = 0; i < n; i++) {
+    int bit = n >> 1;
+    for (; j & bit; bit >>= 1)
+      j ^= bit;
+    j ^= bit;
+    if (i < j) {
+      double t = re[i]; re[i] = re[j]; re[j] = t;
+      t = im[i]; im[i] = im[j]; im[j] = t;
+    }
+  }
+  for (len = 2; len <= n; len <<= 1) {
+    int half = len >> 1;
+    for (j = 0; j < half; j++) {
+      double ang = sign * 2. * M_PI * j / len;
+      double wr = cos (ang), wi = sin (ang);
+      for (i = j; i < n; i += len) {
+        double xr = re[i + half] * wr - im[i + half] * wi;
+        double xi = re[i + half] * wi + im[i + half] * wr;
+        re[i + half] = re[i] - xr;
+        im[i + half] = im[i] - xi;
+        re[i] += xr;
+        im[i] += xi;
+      }
+    }
+  }
+}
+
+/* real input -> n/2+1 bins (gst_fft_f64_fft semantics) */
+static void
+real_dft (const double *x, int n, double *out_re, double *out_im)
+{
+  double re[ORC_FFT_FRAME], im[ORC_FFT_FRAME];
+  int k;
+  memcpy (re, x, n * sizeof (double));
+  memset (im, 0, n * sizeof (double));
+  orc_fft (re, im, n, -1);
+  for (k = 0; k <= n / 2; k++) {
+    out_re[k] = re[k];
+    out_im[k] = im[k];
+  }
+}
+
+/* n/2+1 bins -> n real samples, unnormalised (gst_fft_f64_inverse_fft) */
+static void
+real_idft (const double *in_re, const double *in_im, int n, double *x)
+{
+  double re[ORC_FFT_FRAME], im[ORC_FFT_FRAME];
+  int k;
+  for (k = 0; k <= n / 2; k++) {
+    re[k] = in_re[k];
+    im[k] = in_im[k];
+  }
+  for (k = n / 2 + 1; k < n; k++) {
+    re[k] = in_re[n - k];
+    im[k] = -in_im[n - k];
+  }
+  orc_fft (re, im, n, +1);
+  memcpy (x, re, n * sizeof (double));
+}
+
+/* ======================================================================== */
+/* band tables: earmodel.c:279-323 (params_set_bands), :627-635, :702-709     */
+/* ======================================================================== */
+
+static double
+time_constant (double fc, int step, double tau_min, double tau_100)
+{
+  /* earmodel.c:627-635 */
+  double tau = tau_min + 100. / fc * (tau_100 - tau_min);
+  return exp (step / (-48000. * tau));
+}
+
+static double
+ear_weight (double f_hz)
+{
+  /* earmodel.c:702-709 */
+  double f = f_hz / 1000.;
+  double w_db = -0.6 * 3.64 * pow (f, -0.8) + 6.5 * exp (-0.6 * pow (f - 3.3, 2))
+    - 1e-3 * pow (f, 3.6);
+  return pow (10, w_db / 20);
+}
+
+static void
+bands_fill (orc_bands *b, const double *fc, int bands, int step,
+            double loudness_scale, double tau_min, double tau_100)
+{
+  int i;
+  b->bands = bands;
+  b->step = step;
+  for (i = 0; i < bands; i++) {
+    double f = fc[i];
+    b->fc[i] = f;
+    /* earmodel.c:303-316 */
+    b->internal_noise[i] = pow (10., 0.4 * 0.364 * pow (f / 1000., -0.8));
+    b->exc_threshold[i] = pow (10., 0.364 * pow (f / 1000., -0.8));
+    b->threshold[i] = pow (10., 0.1 * (-2. - 2.05 * atan (f / 4000.)
+                                        - 0.75 * atan (f / 1600. * f / 1600.)));
+    b->loud_factor[i] = loudness_scale *
+      pow (b->exc_threshold[i] / (1e4 * b->threshold[i]), 0.23);
+    b->ear_tc[i] = time_constant (f, step, tau_min, tau_100);
+    /* leveladapter.c:203-206, modpatt.c:182-186 */
+    b->adapt_tc[i] = time_constant (f, step, 0.008, 0.05);
+  }
+}
+
+double
+orc_loudness (const orc_bands *b, const double *excitation)
+{
+  /* earmodel.c:891-907 */
+  double total = 0.;
+  int i;
+  for (i = 0; i < b->bands; i++) {
+    double l = b->loud_factor[i] *
+      (pow (1. - b->threshold[i] + b->threshold[i] * excitation[i] / b->exc_threshold[i], 0.23) - 1.);
+    total += MAXF (l, 0.);
+  }
+  return total * 24. / b->bands;
+}
+
+/* ======================================================================== */
+/* FFT ear model                                                              */
+/* ======================================================================== */
+
+static void
+spread_bands (const orc_fftmodel *m, const double *pp, double *e2)
+{
+  /* fftearmodel.c:637-676 (do_spreading), Kabal section 2.8 */
+  int nb = m->b.bands, i, j;
+  double up_e[ORC_MAXBANDS], en_e[ORC_MAXBANDS];
+  for (i = 0; i < nb; i++) {
+    double a_uce = m->aUC[i] * pow (pp[i], 0.2 * m->delta_z);
+    double g_iu = (1. - pow (a_uce, nb - i)) / (1. - a_uce);
+    double en = pp[i] / (m->gIL[i] + g_iu - 1.);
+    up_e[i] = pow (a_uce, 0.4);
+    en_e[i] = pow (en, 0.4);
+  }
+  e2[nb - 1] = en_e[nb - 1];
+  for (i = nb - 1; i > 0; i--)
+    e2[i - 1] = m->aLe * e2[i] + en_e[i - 1];
+  for (i = 0; i < nb - 1; i++) {
+    double r = en_e[i];
+    for (j = i + 1; j < nb; j++) {
+      r *= up_e[i];
+      e2[j] += r;
+    }
+  }
+  for (i = 0; i < nb; i++)
+    e2[i] = pow (e2[i], 1. / 0.4) / m->spread_norm[i];
+}
+
+void
+orc_fftmodel_init (orc_fftmodel *m, int bands, double level_db)
+{
+  const double gamma = 0.84971762641205;       /* fftearmodel.c:52 */
+  const int n = ORC_FFT_FRAME;
+  double fc[ORC_MAXBANDS], ones[ORC_MAXBANDS], sp[ORC_MAXBANDS];
+  double z_lo = 7. * asinh (80. / 650.), z_hi = 7. * asinh (18000. / 650.);
+  double a_l;
+  int k, i;
+
+  memset (m, 0, sizeof *m);
+  /* fftearmodel.c:167-172: Hann window incl. sqrt(8/3), N-1 in the denominator */
+  for (k = 0; k < n; k++)
+    m->hann[k] = sqrt (8. / 3.) * 0.5 * (1. - cos (2 * M_PI * k / (n - 1)));
+  /* fftearmodel.c:253-256: squared outer/middle ear weight per bin */
+  for (k = 0; k <= n / 2; k++)
+    m->ear_weight2[k] = pow (ear_weight ((double) k * FS / n), 2);
+  /* fftearmodel.c:312-313 */
+  m->level_factor = pow (10, level_db / 10) /
+    (8. / 3. * (gamma / 4 * (n - 1)) * (gamma / 4 * (n - 1)));
+
+  /* fftearmodel.c:701-773 */
+  m->delta_z = 27. / (bands - 1);
+  a_l = pow (10., -2.7 * m->delta_z);
+  m->aLe = pow (a_l, 0.4);
+  for (i = 0; i < bands; i++) {
+    double zl = z_lo + i * m->delta_z;
+    double zu = MINF (z_hi, z_lo + (i + 1) * m->delta_z);
+    double zc = (zu + zl) / 2.;
+    double fl = 650. * sinh (zl / 7.), fu = 650. * sinh (zu / 7.);
+    double edge;
+    fc[i] = 650. * sinh (zc / 7.);
+    m->lo[i] = (int) round (fl / FS * n);
+    m->hi[i] = (int) round (fu / FS * n);
+    edge = (2 * m->lo[i] + 1) / 2. * FS / n;
+    if (edge > fu)
+      edge = fu;
+    m->wlo[i] = (edge - fl) * n / FS;
+    if (m->lo[i] == m->hi[i]) {
+      m->whi[i] = 0;
+    } else {
+      edge = (2 * m->hi[i] - 1) / 2. * FS / n;
+      m->whi[i] = (fu - edge) * n / FS;
+    }
+    m->aUC[i] = pow (10., (-2.4 - 23. / fc[i]) * m->delta_z);
+    m->gIL[i] = (1. - pow (a_l, i + 1)) / (1. - a_l);
+    m->spread_norm[i] = 1.;
+    m->mask_diff[i] = pow (10., (i * m->delta_z <= 12. ? 3. : 0.25 * i * m->delta_z) / 10.);
+    ones[i] = 1.;
+  }
+  /* fftearmodel.c:53,224-228: loudness scale, (8 ms, 30 ms), hop 1024 */
+  bands_fill (&m->b, fc, bands, n / 2, 1.07664, 0.008, 0.030);
+  /* fftearmodel.c:778-781: normalisation = spreading of an all-ones pattern */
+  spread_bands (m, ones, sp);
+  memcpy (m->spread_norm, sp, bands * sizeof (double));
+}
+
+void
+orc_fftstate_reset (orc_fftstate *s)
+{
+  memset (s, 0, sizeof *s);      /* fftearmodel.c:319-322 */
+}
+
+void
+orc_fftmodel_group (const orc_fftmodel *m, const double *spec, double *out)
+{
+  /* fftearmodel.c:604-620 */
+  int i, k;
+  for (i = 0; i < m->b.bands; i++) {
+    double p = m->wlo[i] * spec[m->lo[i]] + m->whi[i] * spec[m->hi[i]];
+    for (k = m->lo[i] + 1; k < m->hi[i]; k++)
+      p += spec[k];
+    out[i] = p < 1e-12 ? 1e-12 : p;
+  }
+}
+
+void
+orc_fftmodel_process (const orc_fftmodel *m, orc_fftstate *s, const float *x)
+{
+  /* fftearmodel.c:433-515 */
+  double win[ORC_FFT_FRAME], fr[ORC_FFT_BINS], fi[ORC_FFT_BINS];
+  double bp[ORC_MAXBANDS], pp[ORC_MAXBANDS], energy = 0.;
+  int k, i, nb = m->b.bands;
+
+  for (k = 0; k < ORC_FFT_FRAME; k++)
+    win[k] = m->hann[k] * x[k];
+  real_dft (win, ORC_FFT_FRAME, fr, fi);
+  for (k = 0; k < ORC_FFT_BINS; k++) {
+    s->power[k] = (fr[k] * fr[k] + fi[k] * fi[k]) * m->level_factor;
+    s->weighted[k] = s->power[k] * m->ear_weight2[k];
+  }
+  orc_fftmodel_group (m, s->weighted, bp);
+  for (i = 0; i < nb; i++)
+    pp[i] = bp[i] + m->b.internal_noise[i];
+  spread_bands (m, pp, s->unsmeared);
+  for (i = 0; i < nb; i++) {
+    double a = m->b.ear_tc[i];
+    s->filtered[i] = a * s->filtered[i] + (1. - a) * s->unsmeared[i];
+    s->excitation[i] = s->filtered[i] > s->unsmeared[i] ? s->filtered[i] : s->unsmeared[i];
+  }
+  /* fftearmodel.c:508-514; the product is formed in single precision there
+   * (gfloat * gfloat) and accumulated in double */
+  for (k = ORC_FFT_FRAME / 2; k < ORC_FFT_FRAME; k++) {
+    float sq = x[k] * x[k];
+    energy += sq;
+  }
+  s->energy_reached = energy >= 8000. / (32768. * 32768.);
+}
+
+/* ======================================================================== */
+/* filter-bank ear model: fbearmodel.c                                        */
+/* ======================================================================== */
+
+static const int fb_len[ORC_FB_BANDS] = {      /* BS.1387 Table 8; fbearmodel.c:57-61 */
+  1456, 1438, 1406, 1362, 1308, 1244, 1176, 1104, 1030, 956, 884, 814, 748,
+  686, 626, 570, 520, 472, 430, 390, 354, 320, 290, 262, 238, 214, 194, 176,
+  158, 144, 130, 118, 106, 96, 86, 78, 70, 64, 58, 52
+};
+
+#define FB_RING 1456
+#define FB_SLOPE_A 0.993355506255034           /* fbearmodel.c:49 */
+#define FB_DIST 0.921851456499719              /* fbearmodel.c:50 */
+#define FB_CL 0.0802581846102741               /* fbearmodel.c:51 */
+
+void
+orc_fbmodel_init (orc_fbmodel *m, double level_db)
+{
+  double fc[ORC_FB_BANDS];
+  int band, n;
+  memset (m, 0, sizeof *m);
+  m->level_factor = pow (10., level_db / 20.);      /* fbearmodel.c:252-253 */
+  for (n = 0; n < 6; n++)                           /* fbearmodel.c:182-185 */
+    m->back_mask[n] = cos (M_PI * (n - 5.) / 12.) * cos (M_PI * (n - 5.) / 12.) * 0.9761 / 6.;
+  for (band = 0; band < ORC_FB_BANDS; band++) {
+    /* fbearmodel.c:201-220 */
+    int len = fb_len[band];
+    double wt;
+    fc[band] = sinh ((asinh (50. / 650.) +
+                      band * (asinh (18000. / 650.) - asinh (50. / 650.)) / 39.)) * 650.;
+    wt = ear_weight (fc[band]);
+    m->flen[band] = len;
+    m->h_re[band] = (double *) malloc ((len / 2 + 1) * sizeof (double));
+    m->h_im[band] = (double *) malloc ((len / 2 + 1) * sizeof (double));
+    for (n = 0; n < len / 2 + 1; n++) {
+      double win = 4. / len * sin (M_PI * n / len) * sin (M_PI * n / len) * wt;
+      m->h_re[band][n] = win * cos (2 * M_PI * fc[band] * (n - len / 2.) / 48000.);
+      m->h_im[band][n] = win * sin (2 * M_PI * fc[band] * (n - len / 2.) / 48000.);
+    }
+  }
+  /* fbearmodel.c:171-177 */
+  bands_fill (&m->b, fc, ORC_FB_BANDS, ORC_FB_FRAME, 1.26539, 0.004, 0.020);
+}
+
+void
+orc_fbmodel_free (orc_fbmodel *m)
+{
+  int b;
+  for (b = 0; b < ORC_FB_BANDS; b++) {
+    free (m->h_re[b]);
+    free (m->h_im[b]);
+  }
+}
+
+void
+orc_fbstate_reset (orc_fbstate *s)
+{
+  memset (s, 0, sizeof *s);
+}
+
+static void
+fb_filter (const orc_fbmodel *m, const orc_fbstate *s, double *out_re, double *out_im)
+{
+  /* fbearmodel.c:399-435.  ring[ring_pos + d] holds the input delayed by d
+   * samples for d < 1456; the reference reads up to d = 1456 for band 0, which
+   * aliases onto the newest sample in the doubled buffer -- reproduced as is. */
+  int band, n;
+  for (band = 0; band < ORC_FB_BANDS; band++) {
+    int len = m->flen[band], half = len / 2;
+    int delay = 1 + (fb_len[0] - len) / 2;         /* (31) in BS.1387 */
+    const double *p1 = s->ring + s->ring_pos + delay;
+    const double *p2 = p1 + len;
+    const double *hr = m->h_re[band], *hi = m->h_im[band];
+    double re = 0, im = 0;
+    for (n = 1; n < half; n++) {
+      re += (p1[n] + p2[-n]) * hr[n];
+      im += (p1[n] - p2[-n]) * hi[n];
+    }
+    re += p1[half] * hr[half];
+    im += p1[half] * hi[half];
+    out_re[band] = re;
+    out_im[band] = im;
+  }
+}
+
+void
+orc_fbmodel_process (const orc_fbmodel *m, orc_fbstate *s, const float *x)
+{
+  /* fbearmodel.c:276-396 */
+  int k, band, j;
+  for (k = 0; k < ORC_FB_FRAME; k++) {
+    double in = x[k] * m->level_factor;
+    /* two cascaded DC-rejection biquads, fbearmodel.c:292-303 */
+    double y1 = in - 2. * s->hp1_x1 + s->hp1_x2 + 1.99517 * s->hp1_y1 - 0.995174 * s->hp1_y2;
+    double y2 = y1 - 2. * s->hp1_y1 + s->hp1_y2 + 1.99799 * s->hp2_y1 - 0.997998 * s->hp2_y2;
+    s->hp1_x2 = s->hp1_x1;
+    s->hp1_x1 = in;
+    s->hp1_y2 = s->hp1_y1;
+    s->hp1_y1 = y1;
+    s->hp2_y2 = s->hp2_y1;
+    s->hp2_y1 = y2;
+    if (s->ring_pos == 0)
+      s->ring_pos = FB_RING;
+    s->ring_pos--;
+    s->ring[s->ring_pos] = y2;
+    s->ring[s->ring_pos + FB_RING] = y2;
+    if (k % 32 == 0) {
+      double fr[ORC_FB_BANDS], fi[ORC_FB_BANDS], ar[ORC_FB_BANDS], ai[ORC_FB_BANDS];
+      fb_filter (m, s, fr, fi);
+      memcpy (ar, fr, sizeof ar);
+      memcpy (ai, fi, sizeof ai);
+      /* frequency-domain spreading, fbearmodel.c:327-354 */
+      for (band = 0; band < ORC_FB_BANDS; band++) {
+        double level = 10 * log10 (fr[band] * fr[band] + fi[band] * fi[band]);
+        double slope = MAXF (4, 24 + 230 / m->b.fc[band] - 0.2 * level);
+        double dist_s = pow (FB_DIST, slope);
+        double d1 = fr[band], d2 = fi[band];
+        s->cu[band] = s->cu[band] + FB_SLOPE_A * (dist_s - s->cu[band]);
+        for (j = band + 1; j < ORC_FB_BANDS; j++) {
+          d1 *= s->cu[band];
+          d2 *= s->cu[band];
+          ar[j] += d1;
+          ai[j] += d2;
+        }
+      }
+      for (band = ORC_FB_BANDS - 1; band > 0; band--) {
+        ar[band - 1] += FB_CL * ar[band];
+        ai[band - 1] += FB_CL * ai[band];
+      }
+      /* rectification + history for the backward-masking FIR, :357-368 */
+      for (band = 0; band < ORC_FB_BANDS; band++) {
+        memmove (s->e0_hist[band] + 1, s->e0_hist[band], 10 * sizeof (double));
+        s->e0_hist[band][0] = ar[band] * ar[band] + ai[band] * ai[band];
+      }
+    }
+  }
+  for (band = 0; band < ORC_FB_BANDS; band++) {
+    /* fbearmodel.c:371-395 */
+    double e1 = 0., a = m->b.ear_tc[band];
+    for (j = 0; j < 5; j++)
+      e1 += (s->e0_hist[band][j] + s->e0_hist[band][10 - j]) * m->back_mask[j];
+    e1 += s->e0_hist[band][5] * m->back_mask[5];
+    s->unsmeared[band] = e1 + m->b.internal_noise[band];
+    s->excitation[band] = a * s->excitation[band] + (1. - a) * s->unsmeared[band];
+  }
+}
+
+/* ======================================================================== */
+/* level / pattern adaptation: leveladapter.c:243-340                         */
+/* ======================================================================== */
+
+void
+orc_leveladapt_reset (orc_leveladapt *l)
+{
+  memset (l, 0, sizeof *l);      /* leveladapter.c:191-198: all state starts at 0 */
+}
+
+void
+orc_leveladapt_process (const orc_bands *b, orc_leveladapt *l,
+                        const double *ref, const double *test)
+{
+  int nb = b->bands, k, i;
+  double num = 0., den = 0., lev, pa_ref[ORC_MAXBANDS], pa_test[ORC_MAXBANDS];
+  double lc_ref[ORC_MAXBANDS], lc_test[ORC_MAXBANDS];
+  int m1_max = nb / 36, m2_max = nb / 25;        /* :315-316 */
+
+  for (k = 0; k < nb; k++) {
+    double a = b->adapt_tc[k];
+    l->filt_ref[k] = a * l->filt_ref[k] + (1 - a) * ref[k];
+    l->filt_test[k] = a * l->filt_test[k] + (1 - a) * test[k];
+    num += sqrt (l->filt_ref[k] * l->filt_test[k]);
+    den += l->filt_test[k];
+  }
+  lev = num * num / (den * den);
+  for (k = 0; k < nb; k++) {
+    if (lev > 1) {                               /* :278-290 */
+      lc_ref[k] = ref[k] / lev;
+      lc_test[k] = test[k];
+    } else {
+      lc_ref[k] = ref[k];
+      lc_test[k] = test[k] * lev;
+    }
+  }
+  for (k = 0; k < nb; k++) {
+    double a = b->adapt_tc[k];
+    /* :293-298: no (1-a) gain on the input terms */
+    l->filt_num[k] = a * l->filt_num[k] + lc_test[k] * lc_ref[k];
+    l->filt_den[k] = a * l->filt_den[k] + lc_ref[k] * lc_ref[k];
+    if (l->filt_num[k] >= l->filt_den[k]) {
+      pa_ref[k] = 1.;
+      pa_test[k] = l->filt_den[k] / l->filt_num[k];
+    } else {
+      pa_ref[k] = l->filt_num[k] / l->filt_den[k];
+      pa_test[k] = 1.;
+    }
+  }
+  for (k = 0; k < nb; k++) {
+    double a = b->adapt_tc[k], rr = 0., rt = 0.;
+    int m1 = k < m1_max ? k : m1_max;
+    int m2 = (nb - k - 1) < m2_max ? (nb - k - 1) : m2_max;
+    for (i = k - m1; i <= k + m2; i++) {
+      rr += pa_ref[i];
+      rt += pa_test[i];
+    }
+    rr /= (m1 + m2 + 1);
+    rt /= (m1 + m2 + 1);
+    l->pattcorr_ref[k] = a * l->pattcorr_ref[k] + (1 - a) * rr;
+    l->pattcorr_test[k] = a * l->pattcorr_test[k] + (1 - a) * rt;
+    l->adapted_ref[k] = lc_ref[k] * l->pattcorr_ref[k];
+    l->adapted_test[k] = lc_test[k] * l->pattcorr_test[k];
+  }
+}
+
+/* ======================================================================== */
+/* modulation patterns: modpatt.c:223-251                                     */
+/* ======================================================================== */
+
+void
+orc_modproc_reset (orc_modproc *m)
+{
+  memset (m, 0, sizeof *m);
+}
+
+void
+orc_modproc_process (const orc_bands *b, orc_modproc *m, const double *unsmeared)
+{
+  double dfac = 48000. / b->step;
+  int k;
+  for (k = 0; k < b->bands; k++) {
+    double a = b->adapt_tc[k];
+    double loud = pow (unsmeared[k], 0.3);
+    double dl = dfac * fabs (loud - m->prev_loud[k]);
+    m->filt_dloud[k] = a * m->filt_dloud[k] + (1 - a) * dl;
+    m->filt_loud[k] = a * m->filt_loud[k] + (1. - a) * loud;
+    m->modulation[k] = m->filt_dloud[k] / (1. + m->filt_loud[k] / 0.3);
+    m->prev_loud[k] = loud;
+  }
+}
+
+/* ======================================================================== */
+/* MOV accumulators: movaccum.c:317-481                                       */
+/* ======================================================================== */
+
+void
+orc_acc_init (orc_movaccum *a, int mode, int channels)
+{
+  int c, i;
+  memset (a, 0, sizeof *a);
+  a->mode = mode;
+  a->channels = channels;
+  a->status = ORC_ST_INIT;
+  for (c = 0; c < 2; c++)
+    for (i = 0; i < 3; i++)
+      a->live[c].past[i] = NAN;               /* movaccum.c:293 */
+}
+
+void
+orc_acc_set_tentative (orc_movaccum *a, int tentative)
+{
+  /* movaccum.c:317-362 */
+  int c;
+  if (!tentative) {
+    a->status = ORC_ST_NORMAL;
+    return;
+  }
+  if (a->status != ORC_ST_NORMAL)
+    return;
+  for (c = 0; c < a->channels; c++) {
+    if (a->mode == ORC_FILTERED_MAX) {
+      a->saved[c].max = a->live[c].max;       /* filter state is NOT snapshotted */
+    } else {
+      a->saved[c].num = a->live[c].num;
+      a->saved[c].den = a->live[c].den;
+      a->saved[c].num2 = a->live[c].num2;
+    }
+  }
+  a->status = ORC_ST_TENTATIVE;
+}
+
+void
+orc_acc_add (orc_movaccum *a, int c, double val, double w)
+{
+  /* movaccum.c:368-425 */
+  orc_accdata *d = &a->live[c];
+  if (a->status == ORC_ST_INIT)
+    return;
+  switch (a->mode) {
+    case ORC_RMS:
+      w *= w;
+      d->num += w * val * val;
+      d->den += w;
+      break;
+    case ORC_RMS_ASYM:
+      d->num += val * val;
+      d->num2 += w * w;
+      d->den += 1.;
+      break;
+    case ORC_AVG:
+    case ORC_AVG_LOG:
+    case ORC_ADB:
+      d->num += w * val;
+      d->den += w;
+      break;
+    case ORC_AVG_WINDOW: {
+      double sq = sqrt (val);
+      if (!isnan (d->past[0])) {
+        /* the reference adds past[0], past[1], past[2] to val_sqrt in that order */
+        double ws = ((sq + d->past[0]) + d->past[1]) + d->past[2];
+        ws /= 4.;
+        ws *= ws;
+        ws *= ws;
+        d->num += ws;
+        d->den += 1.;
+      }
+      d->past[0] = d->past[1];
+      d->past[1] = d->past[2];
+      d->past[2] = sq;
+      break;
+    }
+    case ORC_FILTERED_MAX:
+      d->filt = 0.9 * d->filt + 0.1 * val;
+      if (d->filt > d->max)
+        d->max = d->filt;
+      break;
+  }
+}
+
+double
+orc_acc_value (const orc_movaccum *a)
+{
+  /* movaccum.c:438-481 */
+  const orc_accdata *d = a->status == ORC_ST_TENTATIVE ? a->saved : a->live;
+  double v = 0.;
+  int c;
+  for (c = 0; c < a->channels; c++) {
+    switch (a->mode) {
+      case ORC_AVG:
+        v += d[c].num / d[c].den;
+        break;
+      case ORC_AVG_LOG:
+        v += 10. * log10 (d[c].num / d[c].den);
+        break;
+      case ORC_AVG_WINDOW:
+      case ORC_RMS:
+        v += sqrt (d[c].num / d[c].den);
+        break;
+      case ORC_RMS_ASYM:
+        v += sqrt (d[c].num / d[c].den);
+        v += 0.5 * sqrt (d[c].num2 / d[c].den);
+        break;
+      case ORC_FILTERED_MAX:
+        v += d[c].max;
+        break;
+      case ORC_ADB:
+        if (d[c].den > 0)
+          v += d[c].num == 0. ? -0.5 : log10 (d[c].num / d[c].den);
+        break;
+    }
+  }
+  return v / a->channels;
+}
+
+/* ======================================================================== */
+/* neural network: nn.c:40-93, 187-216, 304-335, 372-375                      */
+/* ======================================================================== */
+
+static const double nb_amin[11] = { 393.916656, 361.965332, -24.045116, 1.110661, -0.206623,
+  0.074318, 1.113683, 0.950345, 0.029985, 0.000101, 0. };
+static const double nb_amax[11] = { 921, 881.131226, 16.212030, 107.137772, 2.886017,
+  13.933351, 63.257874, 1145.018555, 14.819740, 1., 1. };
+static const double nb_wx[11][3] = {
+  {-0.502657, 0.436333, 1.219602}, {4.307481, 3.246017, 1.123743},
+  {4.984241, -2.211189, -0.192096}, {0.051056, -1.762424, 4.331315},
+  {2.321580, 1.789971, -0.754560}, {-5.303901, -3.452257, -10.814982},
+  {2.730991, -6.111805, 1.519223}, {0.624950, -1.331523, -5.955151},
+  {3.102889, 0.871260, -5.922878}, {-1.051468, -0.939882, -0.142913},
+  {-1.804679, -0.503610, -0.620456} };
+static const double nb_wxb[3] = { -2.518254, 0.654841, -2.207228 };
+static const double nb_wy[3] = { -3.817048, 4.107138, 4.629582 };
+static const double nb_wyb = -0.307594;
+
+static const double na_amin[5] = { 13.298751, 0.041073, -25.018791, 0.061560, 0.02452 };
+static const double na_amax[5] = { 2166.5, 13.24326, 13.46708, 10.226771, 14.224874 };
+static const double na_wx[5][5] = {
+  {21.211773, -39.013052, -1.382553, -14.545348, -0.320899},
+  {-8.981803, 19.956049, 0.935389, -1.686586, -3.238586},
+  {1.633830, -2.877505, -7.442935, 5.606502, -1.783120},
+  {6.103821, 19.587435, -0.240284, 1.088213, -0.511314},
+  {11.556344, 3.892028, 9.720441, -3.287205, -11.031250} };
+static const double na_wxb[5] = { 1.330890, 2.686103, 2.096598, -1.327851, 3.087055 };
+static const double na_wy[5] = { -4.696996, -3.289959, 7.004782, 6.651897, 4.009144 };
+static const double na_wyb = -1.360308;
+
+double
+orc_di_basic (const double *mv)
+{
+  double x[3], di = nb_wyb;
+  int i, j;
+  for (j = 0; j < 3; j++)
+    x[j] = nb_wxb[j];
+  for (i = 0; i < 11; i++) {
+    double m = (mv[i] - nb_amin[i]) / (nb_amax[i] - nb_amin[i]);   /* no clamping: CLAMP_MOVS 0 */
+    for (j = 0; j < 3; j++)
+      x[j] += nb_wx[i][j] * m;
+  }
+  for (j = 0; j < 3; j++)
+    di += nb_wy[j] / (1 + exp (-x[j]));
+  return di;
+}
+
+double
+orc_di_advanced (const double *mv)
+{
+  double x[5], di = na_wyb;
+  int i, j;
+  for (j = 0; j < 5; j++)
+    x[j] = na_wxb[j];
+  for (i = 0; i < 5; i++) {
+    double m = (mv[i] - na_amin[i]) / (na_amax[i] - na_amin[i]);
+    for (j = 0; j < 5; j++)
+      x[j] += na_wx[i][j] * m;
+  }
+  for (j = 0; j < 5; j++)
+    di += na_wy[j] / (1 + exp (-x[j]));
+  return di;
+}
+
+double
+orc_odg (double di)
+{
+  return -3.98 + (0.22 - -3.98) / (1 + exp (-di));
+}
+
+/* ======================================================================== */
+/* the element's per-frame orchestration                                      */
+/* ======================================================================== */
+
+typedef struct { float *buf; size_t len, cap, head; } fifo;   /* GstAdapter stand-in (floats) */
+
+static void
+fifo_push (fifo *f, const float *d, size_t n)
+{
+  if (f->head > 0 && f->head == f->len) {
+    f->head = f->len = 0;
+  }
+  if (f->len + n > f->cap) {
+    /* compact, then grow */
+    size_t live = f->len - f->head;
+    if (f->head > 0) {
+      memmove (f->buf, f->buf + f->head, live * sizeof (float));
+      f->head = 0;
+      f->len = live;
+    }
+    if (f->len + n > f->cap) {
+      f->cap = (f->len + n) * 2 + 4096;
+      f->buf = (float *) realloc (f->buf, f->cap * sizeof (float));
+    }
+  }
+  memcpy (f->buf + f->len, d, n * sizeof (float));
+  f->len += n;
+}
+
+static size_t fifo_avail (const fifo *f) { return f->len - f->head; }
+static float *fifo_peek (fifo *f) { return f->buf + f->head; }
+static void fifo_drop (fifo *f, size_t n) { f->head += n; }
+
+enum { MB_BW_REF, MB_BW_TEST, MB_NMR, MB_WINMOD, MB_ADB, MB_EHS, MB_AVGMOD1, MB_AVGMOD2,
+  MB_NOISELOUD, MB_MFPD, MB_RELDIST, MB_COUNT };            /* gstpeaq.c:95-108 */
+enum { MA_RMSMOD, MA_NLASYM, MA_SEGNMR, MA_EHS, MA_LINDIST, MA_COUNT };   /* gstpeaq.c:86-93 */
+
+struct orc_session {
+  int advanced, channels;
+  fifo ref_fft, test_fft, ref_fb, test_fb;
+  unsigned frame_counter, frame_counter_fb, loudness_reached;
+  orc_fftmodel fftm;
+  orc_fbmodel fbm;
+  orc_fftstate ref_fft_st[2], test_fft_st[2];
+  orc_fbstate *ref_fb_st, *test_fb_st;         /* [channels], advanced only */
+  orc_leveladapt lev[2];
+  orc_modproc ref_mod[2], test_mod[2];
+  orc_movaccum acc[MB_COUNT];
+  double sig_energy, noise_energy;
+};
+
+static int
+frame_above_threshold (const float *x, int n, int channels)
+{
+  /* gstpeaq.c:1081-1099: a FLOAT running sum of |x| over 5 samples, tested from
+   * i = 5 on; fabs() promotes to double, the += rounds back to float. */
+  int c, i;
+  for (c = 0; c < channels; c++) {
+    float sum = 0;
+    for (i = 0; i < 5; i++)
+      sum += fabs (x[channels * i + c]);
+    while (i < n) {
+      sum += fabs (x[channels * i + c]) - fabs (x[channels * (i - 5) + c]);
+      if (sum >= 200. / 32768)
+        return 1;
+      i++;
+    }
+  }
+  return 0;
+}
+
+static void
+deinterleave (const float *x, int n, int channels, int c, float *out)
+{
+  int i;
+  for (i = 0; i < n; i++)               /* gstpeaq.c:799-809 */
+    out[i] = x[channels * i + c];
+}
+
+static double
+noise_loudness (const orc_bands *b, double alpha, double thres_fac, double s0, double nl_min,
+                const double *mod_ref, const double *mod_test,
+                const double *e_ref, const double *e_test)
+{
+  /* movs.c:709-743 */
+  double nl = 0.;
+  int i;
+  for (i = 0; i < b->bands; i++) {
+    double sref = thres_fac * mod_ref[i] + s0;
+    double stest = thres_fac * mod_test[i] + s0;
+    double ethres = b->internal_noise[i];
+    double beta = exp (-alpha * (e_test[i] - e_ref[i]) / e_ref[i]);
+    nl += pow (ethres / stest, 0.23) *
+      (pow (1. + MAXF (stest * e_test[i] - sref * e_ref[i], 0.) /
+            (ethres + sref * e_ref[i] * beta), 0.23) - 1.);
+  }
+  nl *= 24. / b->bands;
+  return nl < nl_min ? 0. : nl;
+}
+
+static void
+mov_moddiff (orc_session *s, const orc_bands *b, orc_movaccum *a1, orc_movaccum *a2,
+             orc_movaccum *awin)
+{
+  /* movs.c:205-254 */
+  double lev_wt = a2 ? 100. : 1.;
+  int c, i;
+  for (c = 0; c < a1->channels; c++) {
+    const double *mr = s->ref_mod[c].modulation, *mt = s->test_mod[c].modulation;
+    const double *lr = s->ref_mod[c].filt_loud;
+    double d1 = 0., d2 = 0., wt = 0.;
+    for (i = 0; i < b->bands; i++) {
+      double diff = fabs (mr[i] - mt[i]);
+      d1 += diff / (1. + mr[i]);
+      d2 += (mt[i] >= mr[i] ? 1. : .1) * diff / (0.01 + mr[i]);
+      wt += lr[i] / (lr[i] + lev_wt * pow (b->internal_noise[i], 0.3));
+    }
+    if (a1->mode == ORC_RMS)
+      d1 *= 100. / sqrt (b->bands);
+    else
+      d1 *= 100. / b->bands;
+    d2 *= 100. / b->bands;
+    orc_acc_add (a1, c, d1, wt);
+    if (a2)
+      orc_acc_add (a2, c, d2, wt);
+    if (awin)
+      orc_acc_add (awin, c, d1, 1.);
+  }
+}
+
+static void
+mov_bandwidth (orc_session *s, orc_movaccum *aref, orc_movaccum *atest)
+{
+  /* movs.c:776-809: unweighted power spectrum */
+  int c, i;
+  for (c = 0; c < aref->channels; c++) {
+    const double *pr = s->ref_fft_st[c].power, *pt = s->test_fft_st[c].power;
+    double thr = pt[921];
+    int bw_ref = 0, bw_test = 0;
+    for (i = 922; i < 1024; i++)
+      if (pt[i] >= thr)
+        thr = pt[i];
+    for (i = 921; i > 0; i--)
+      if (pr[i - 1] > 10. * thr) {
+        bw_ref = i;
+        break;
+      }
+    if (bw_ref > 346) {
+      for (i = bw_ref; i > 0; i--)
+        if (pt[i - 1] >= 3.16227766016838 * thr) {
+          bw_test = i;
+          break;
+        }
+      orc_acc_add (aref, c, bw_ref, 1.);
+      orc_acc_add (atest, c, bw_test, 1.);
+    }
+  }
+}
+
+static void
+mov_nmr (orc_session *s, orc_movaccum *anmr, orc_movaccum *arel)
+{
+  /* movs.c:971-1023: weighted spectra, smeared ref excitation */
+  const orc_fftmodel *m = &s->fftm;
+  int c, i, nb = m->b.bands;
+  for (c = 0; c < anmr->channels; c++) {
+    const double *wr = s->ref_fft_st[c].weighted, *wt = s->test_fft_st[c].weighted;
+    double noise[ORC_FFT_BINS], nib[ORC_MAXBANDS], nmr = 0., nmr_max = 0.;
+    for (i = 0; i < ORC_FFT_BINS; i++)
+      noise[i] = wr[i] - 2 * sqrt (wr[i] * wt[i]) + wt[i];
+    orc_fftmodel_group (m, noise, nib);
+    for (i = 0; i < nb; i++) {
+      double mask = s->ref_fft_st[c].excitation[i] / m->mask_diff[i];
+      double r = nib[i] / mask;
+      nmr += r;
+      if (r > nmr_max)
+        nmr_max = r;
+    }
+    nmr /= nb;
+    if (anmr->mode == ORC_AVG_LOG)
+      orc_acc_add (anmr, c, nmr, 1.);
+    else
+      orc_acc_add (anmr, c, 10. * log10 (nmr), 1.);
+    if (arel)
+      orc_acc_add (arel, c, nmr_max > 1.41253754462275 ? 1. : 0., 1.);
+  }
+}
+
+static void
+mov_prob_detect (orc_session *s, orc_movaccum *aadb, orc_movaccum *amfpd)
+{
+  /* movs.c:1224-1276 */
+  int nb = s->fftm.b.bands, c, i;
+  double p_bin = 1., q_bin = 0.;
+  for (i = 0; i < nb; i++) {
+    double p_band = 0., q_band = 0.;
+    for (c = 0; c < s->channels; c++) {
+      double er = 10. * log10 (s->ref_fft_st[c].excitation[i]);
+      double et = 10. * log10 (s->test_fft_st[c].excitation[i]);
+      double l = 0.3 * MAXF (er, et) + 0.7 * et;
+      double sd = l > 0. ? 5.95072 * pow (6.39468 / l, 1.71332) +
+        9.01033e-11 * pow (l, 4.) + 5.05622e-6 * pow (l, 3.) -
+        0.00102438 * l * l + 0.0550197 * l - 0.198719 : 1e30;
+      double e = er - et;
+      double bexp = er > et ? 4. : 6.;
+      double pc = 1. - pow (0.5, pow (e / sd, bexp));
+      double qc = fabs (trunc (e)) / sd;        /* USE_FLOOR_FOR_STEPS_ABOVE_THRESHOLD 0 */
+      if (pc > p_band)
+        p_band = pc;
+      if (c == 0 || qc > q_band)
+        q_band = qc;
+    }
+    p_bin *= 1. - p_band;
+    q_bin += q_band;
+  }
+  p_bin = 1. - p_bin;
+  if (p_bin > 0.5)
+    orc_acc_add (aadb, 0, q_bin, 1.);
+  orc_acc_add (amfpd, 0, p_bin, 1.);
+}
+
+static void
+mov_ehs (orc_session *s, orc_movaccum *aehs)
+{
+  /* movs.c:1279-1315 (do_xcorr), :1346-1443; settings.h: window not centred,
+   * mean removed before windowing */
+  enum { LAG = 256 };
+  int c, i, valid = 0;
+  for (c = 0; c < aehs->channels; c++)
+    if (s->ref_fft_st[c].energy_reached || s->test_fft_st[c].energy_reached)
+      valid = 1;
+  if (!valid)
+    return;
+  for (c = 0; c < aehs->channels; c++) {
+    const double *fr = s->ref_fft_st[c].weighted, *ft = s->test_fft_st[c].weighted;
+    double d[2 * LAG], t[2 * LAG], corr[2 * LAG];
+    double f1r[LAG + 1], f1i[LAG + 1], f2r[LAG + 1], f2i[LAG + 1];
+    double cr[LAG / 2 + 1], ci[LAG / 2 + 1];
+    double d0, dk, cavg = 0., ehs = 0., prev;
+    for (i = 0; i < 2 * LAG; i++)
+      d[i] = (fr[i] == 0. && ft[i] == 0.) ? 0. : log (ft[i] / fr[i]);
+    /* c[l] = sum_{k<256} d[k] d[k+l] through 512-point DFTs */
+    memcpy (t, d, sizeof t);
+    real_dft (t, 2 * LAG, f1r, f1i);
+    memset (t + LAG, 0, LAG * sizeof (double));
+    real_dft (t, 2 * LAG, f2r, f2i);
+    for (i = 0; i <= LAG; i++) {
+      double r = (f1r[i] * f2r[i] + f1i[i] * f2i[i]) / (2 * LAG);
+      double q = (f2r[i] * f1i[i] - f1r[i] * f2i[i]) / (2 * LAG);
+      f1r[i] = r;
+      f1i[i] = q;
+    }
+    real_idft (f1r, f1i, 2 * LAG, corr);
+    d0 = corr[0];
+    dk = d0;
+    for (i = 0; i < LAG; i++) {
+      corr[i] /= sqrt (d0 * dk);
+      cavg += corr[i];
+      dk += d[i + LAG] * d[i + LAG] - d[i] * d[i];
+    }
+    cavg /= LAG;
+    for (i = 0; i < LAG; i++) {
+      double w = 0.81649658092773 * (1 - cos (2 * M_PI * i / (LAG - 1))) / LAG;
+      corr[i] = (corr[i] - cavg) * w;
+    }
+    real_dft (corr, LAG, cr, ci);
+    prev = cr[0] * cr[0] + ci[0] * ci[0];
+    for (i = 1; i <= LAG / 2; i++) {
+      double cur = cr[i] * cr[i] + ci[i] * ci[i];
+      if (cur > prev && cur > ehs)
+        ehs = cur;
+      prev = cur;
+    }
+    orc_acc_add (aehs, c, 1000. * ehs, 1.);
+  }
+}
+
+static void
+snr_accumulate (orc_session *s, const float *ref, const float *test, int frame)
+{
+  /* gstpeaq.c:913-918: float products, double sums, first half of the interleaved frame */
+  int i, n = s->channels * frame / 2;
+  for (i = 0; i < n; i++) {
+    float sq = ref[i] * ref[i];
+    float df = (ref[i] - test[i]) * (ref[i] - test[i]);
+    s->sig_energy += sq;
+    s->noise_energy += df;
+  }
+}
+
+static void
+preprocess (orc_session *s, const orc_bands *b, int c, const double *er, const double *et,
+            const double *ur, const double *ut, unsigned counter)
+{
+  /* gstpeaq.c:834-845 */
+  orc_leveladapt_process (b, &s->lev[c], er, et);
+  orc_modproc_process (b, &s->ref_mod[c], ur);
+  orc_modproc_process (b, &s->test_mod[c], ut);
+  if (s->loudness_reached == UINT_MAX)
+    if (orc_loudness (b, er) > 0.1 && orc_loudness (b, et) > 0.1)
+      s->loudness_reached = counter;
+}
+
+static void
+fft_frame_basic (orc_session *s, const float *ref, const float *test)
+{
+  /* gstpeaq.c:850-921 */
+  float ch[ORC_FFT_FRAME];
+  const orc_bands *b = &s->fftm.b;
+  int c, i, above = frame_above_threshold (ref, ORC_FFT_FRAME, s->channels);
+  for (i = 0; i < MB_COUNT; i++)
+    orc_acc_set_tentative (&s->acc[i], !above);
+  for (c = 0; c < s->channels; c++) {
+    deinterleave (ref, ORC_FFT_FRAME, s->channels, c, ch);
+    orc_fftmodel_process (&s->fftm, &s->ref_fft_st[c], ch);
+  }
+  for (c = 0; c < s->channels; c++) {
+    deinterleave (test, ORC_FFT_FRAME, s->channels, c, ch);
+    orc_fftmodel_process (&s->fftm, &s->test_fft_st[c], ch);
+  }
+  for (c = 0; c < s->channels; c++)
+    preprocess (s, b, c, s->ref_fft_st[c].excitation, s->test_fft_st[c].excitation,
+                s->ref_fft_st[c].unsmeared, s->test_fft_st[c].unsmeared, s->frame_counter);
+  if (s->frame_counter >= 24)
+    mov_moddiff (s, b, &s->acc[MB_AVGMOD1], &s->acc[MB_AVGMOD2], &s->acc[MB_WINMOD]);
+  /* unsigned arithmetic with a UINT_MAX sentinel, gstpeaq.c:359,880-881 */
+  if (s->frame_counter >= 24 && s->frame_counter - 3 >= s->loudness_reached) {
+    orc_movaccum *a = &s->acc[MB_NOISELOUD];
+    for (c = 0; c < a->channels; c++)        /* movs.c:354-371 */
+      orc_acc_add (a, c, noise_loudness (b, 1.5, 0.15, 0.5, 0.,
+                                         s->ref_mod[c].modulation, s->test_mod[c].modulation,
+                                         s->lev[c].adapted_ref, s->lev[c].adapted_test), 1.);
+  }
+  mov_bandwidth (s, &s->acc[MB_BW_REF], &s->acc[MB_BW_TEST]);
+  mov_nmr (s, &s->acc[MB_NMR], &s->acc[MB_RELDIST]);
+  mov_prob_detect (s, &s->acc[MB_ADB], &s->acc[MB_MFPD]);
+  mov_ehs (s, &s->acc[MB_EHS]);
+  snr_accumulate (s, ref, test, ORC_FFT_FRAME);
+  s->frame_counter++;
+}
+
+static void
+fft_frame_advanced (orc_session *s, const float *ref, const float *test)
+{
+  /* gstpeaq.c:924-962 */
+  float ch[ORC_FFT_FRAME];
+  int c, above = frame_above_threshold (ref, ORC_FFT_FRAME, s->channels);
+  orc_acc_set_tentative (&s->acc[MA_SEGNMR], !above);
+  orc_acc_set_tentative (&s->acc[MA_EHS], !above);
+  for (c = 0; c < s->channels; c++) {
+    deinterleave (ref, ORC_FFT_FRAME, s->channels, c, ch);
+    orc_fftmodel_process (&s->fftm, &s->ref_fft_st[c], ch);
+  }
+  for (c = 0; c < s->channels; c++) {
+    deinterleave (test, ORC_FFT_FRAME, s->channels, c, ch);
+    orc_fftmodel_process (&s->fftm, &s->test_fft_st[c], ch);
+  }
+  mov_nmr (s, &s->acc[MA_SEGNMR], NULL);
+  mov_ehs (s, &s->acc[MA_EHS]);
+  snr_accumulate (s, ref, test, ORC_FFT_FRAME);
+  s->frame_counter++;
+}
+
+static void
+fb_block (orc_session *s, const float *ref, const float *test)
+{
+  /* gstpeaq.c:965-1010 */
+  float ch[ORC_FB_FRAME];
+  const orc_bands *b = &s->fbm.b;
+  int c, above = frame_above_threshold (ref, ORC_FB_FRAME, s->channels);
+  orc_acc_set_tentative (&s->acc[MA_RMSMOD], !above);
+  orc_acc_set_tentative (&s->acc[MA_NLASYM], !above);
+  orc_acc_set_tentative (&s->acc[MA_LINDIST], !above);
+  for (c = 0; c < s->channels; c++) {
+    deinterleave (ref, ORC_FB_FRAME, s->channels, c, ch);
+    orc_fbmodel_process (&s->fbm, &s->ref_fb_st[c], ch);
+  }
+  for (c = 0; c < s->channels; c++) {
+    deinterleave (test, ORC_FB_FRAME, s->channels, c, ch);
+    orc_fbmodel_process (&s->fbm, &s->test_fb_st[c], ch);
+  }
+  for (c = 0; c < s->channels; c++)
+    preprocess (s, b, c, s->ref_fb_st[c].excitation, s->test_fb_st[c].excitation,
+                s->ref_fb_st[c].unsmeared, s->test_fb_st[c].unsmeared, s->frame_counter_fb);
+  if (s->frame_counter_fb >= 125)
+    mov_moddiff (s, b, &s->acc[MA_RMSMOD], NULL, NULL);
+  if (s->frame_counter_fb >= 125 && s->frame_counter_fb - 13 >= s->loudness_reached) {
+    for (c = 0; c < s->channels; c++) {
+      const double *mr = s->ref_mod[c].modulation, *mt = s->test_mod[c].modulation;
+      const double *ar = s->lev[c].adapted_ref, *at = s->lev[c].adapted_test;
+      /* movs.c:551-577 with SWAP_MOD_PATTS_FOR_NOISE_LOUDNESS_MOVS 1 */
+      double nl = noise_loudness (b, 2.5, 0.3, 1., 0.1, mr, mt, ar, at);
+      double mc = noise_loudness (b, 1.5, 0.15, 1., 0., mt, mr, at, ar);
+      /* movs.c:679-706 (same switch): both modulation inputs are the reference's */
+      double ld = noise_loudness (b, 1.5, 0.15, 1., 0., mr, mr, ar, s->ref_fb_st[c].excitation);
+      orc_acc_add (&s->acc[MA_NLASYM], c, nl, mc);
+      orc_acc_add (&s->acc[MA_LINDIST], c, ld, 1.);
+    }
+  }
+  s->frame_counter_fb++;
+}
+
+typedef void (*frame_fn) (orc_session *, const float *, const float *);
+
+static void
+drain (orc_session *s, fifo *r, fifo *t, frame_fn fn, size_t frame, size_t hop)
+{
+  /* gstpeaq.c:596-611 */
+  size_t fl = frame * s->channels, hl = hop * s->channels;
+  while (fifo_avail (r) >= fl && fifo_avail (t) >= fl) {
+    fn (s, fifo_peek (r), fifo_peek (t));
+    fifo_drop (r, hl);
+    fifo_drop (t, hl);
+  }
+}
+
+static void
+drain_all (orc_session *s)
+{
+  /* gstpeaq.c:645-656 */
+  if (s->advanced) {
+    drain (s, &s->ref_fft, &s->test_fft, fft_frame_advanced, ORC_FFT_FRAME, ORC_FFT_FRAME / 2);
+    drain (s, &s->ref_fb, &s->test_fb, fb_block, ORC_FB_FRAME, ORC_FB_FRAME);
+  } else {
+    drain (s, &s->ref_fft, &s->test_fft, fft_frame_basic, ORC_FFT_FRAME, ORC_FFT_FRAME / 2);
+  }
+}
+
+static void
+flush_pair (orc_session *s, fifo *r, fifo *t, frame_fn fn, size_t frame)
+{
+  /* gstpeaq.c:716-745: at most ONE zero-padded frame, leftovers may differ */
+  size_t nr = fifo_avail (r), nt = fifo_avail (t), fl = frame * s->channels;
+  if (nr || nt) {
+    float *pr = (float *) calloc (fl, sizeof (float));
+    float *pt = (float *) calloc (fl, sizeof (float));
+    size_t cr = nr < fl ? nr : fl, ct = nt < fl ? nt : fl;
+    memcpy (pr, fifo_peek (r), cr * sizeof (float));
+    memcpy (pt, fifo_peek (t), ct * sizeof (float));
+    fn (s, pr, pt);
+    fifo_drop (r, cr);
+    fifo_drop (t, ct);
+    free (pr);
+    free (pt);
+  }
+}
+
+orc_session *
+orc_session_new (int advanced, int channels, double level_db)
+{
+  orc_session *s = (orc_session *) calloc (1, sizeof *s);
+  int c, i;
+  s->advanced = advanced;
+  s->channels = channels;
+  s->loudness_reached = UINT_MAX;                    /* gstpeaq.c:359 */
+  orc_fftmodel_init (&s->fftm, advanced ? 55 : 109, level_db);   /* gstpeaq.c:521-526 */
+  for (c = 0; c < 2; c++) {
+    orc_fftstate_reset (&s->ref_fft_st[c]);
+    orc_fftstate_reset (&s->test_fft_st[c]);
+    orc_leveladapt_reset (&s->lev[c]);
+    orc_modproc_reset (&s->ref_mod[c]);
+    orc_modproc_reset (&s->test_mod[c]);
+  }
+  if (advanced) {
+    orc_fbmodel_init (&s->fbm, level_db);
+    s->ref_fb_st = (orc_fbstate *) calloc (channels, sizeof (orc_fbstate));
+    s->test_fb_st = (orc_fbstate *) calloc (channels, sizeof (orc_fbstate));
+    /* gstpeaq.c:528-536; the six unused accumulators keep MODE_AVG */
+    for (i = 0; i < MB_COUNT; i++)
+      orc_acc_init (&s->acc[i], ORC_AVG, channels);
+    orc_acc_init (&s->acc[MA_RMSMOD], ORC_RMS, channels);
+    orc_acc_init (&s->acc[MA_NLASYM], ORC_RMS_ASYM, channels);
+  } else {
+    /* gstpeaq.c:538-557, channel counts :580-584 */
+    static const int modes[MB_COUNT] = { ORC_AVG, ORC_AVG, ORC_AVG_LOG, ORC_AVG_WINDOW, ORC_ADB,
+      ORC_AVG, ORC_AVG, ORC_AVG, ORC_RMS, ORC_FILTERED_MAX, ORC_AVG };
+    for (i = 0; i < MB_COUNT; i++)
+      orc_acc_init (&s->acc[i], modes[i], (i == MB_ADB || i == MB_MFPD) ? 1 : channels);
+  }
+  return s;
+}
+
+void
+orc_session_free (orc_session *s)
+{
+  if (!s)
+    return;
+  free (s->ref_fft.buf);
+  free (s->test_fft.buf);
+  free (s->ref_fb.buf);
+  free (s->test_fb.buf);
+  if (s->advanced) {
+    orc_fbmodel_free (&s->fbm);
+    free (s->ref_fb_st);
+    free (s->test_fb_st);
+  }
+  free (s);
+}
+
+void
+orc_session_push_ref (orc_session *s, const float *d, size_t n)
+{
+  /* gstpeaq.c:626-630 */
+  if (s->advanced)
+    fifo_push (&s->ref_fb, d, n * s->channels);
+  fifo_push (&s->ref_fft, d, n * s->channels);
+  drain_all (s);
+}
+
+void
+orc_session_push_test (orc_session *s, const float *d, size_t n)
+{
+  if (s->advanced)
+    fifo_push (&s->test_fb, d, n * s->channels);
+  fifo_push (&s->test_fft, d, n * s->channels);
+  drain_all (s);
+}
+
+void
+orc_session_flush (orc_session *s)
+{
+  /* gstpeaq.c:764-776 */
+  if (s->advanced) {
+    flush_pair (s, &s->ref_fft, &s->test_fft, fft_frame_advanced, ORC_FFT_FRAME);
+    flush_pair (s, &s->ref_fb, &s->test_fb, fb_block, ORC_FB_FRAME);
+  } else {
+    flush_pair (s, &s->ref_fft, &s->test_fft, fft_frame_basic, ORC_FFT_FRAME);
+  }
+}
+
+int
+orc_session_mov_count (const orc_session *s)
+{
+  return s->advanced ? MA_COUNT : MB_COUNT;
+}
+
+void
+orc_session_results (const orc_session *s, double *movs, double *di, double *odg)
+{
+  /* gstpeaq.c:1013-1078 */
+  double mv[MB_COUNT], d;
+  int i, n = orc_session_mov_count (s);
+  for (i = 0; i < n; i++)
+    mv[i] = orc_acc_value (&s->acc[i]);
+  d = s->advanced ? orc_di_advanced (mv) : orc_di_basic (mv);
+  if (movs)
+    memcpy (movs, mv, n * sizeof (double));
+  if (di)
+    *di = d;
+  if (odg)
+    *odg = orc_odg (d);
+}
+
+double
+orc_session_totalsnr (const orc_session *s)
+{
+  return 10 * log10 (s->sig_energy / s->noise_energy);    /* gstpeaq.c:493-497 */
+}
+
+unsigned
+orc_session_frames (const orc_session *s)
+{
+  return s->frame_counter;
+}
+
+void
+orc_run_pair (int advanced, int channels, double level_db,
+              const float *ref, size_t n_ref, const float *test, size_t n_test,
+              double *movs, double *di, double *odg)
+{
+  orc_session *s = orc_session_new (advanced, channels, level_db);
+  orc_session_push_ref (s, ref, n_ref);
+  orc_session_push_test (s, test, n_test);
+  orc_session_flush (s);
+  orc_session_results (s, movs, di, odg);
+  orc_session_free (s);
+}
