@@ -1302,3 +1302,123 @@ orc_run_pair (int advanced, int channels, double level_db,
   orc_session_results (s, movs, di, odg);
   orc_session_free (s);
 }
+
+/* ======================================================================== */
+/* flat entry points for ctypes (tests only)                                  */
+/* ======================================================================== */
+
+static const orc_bands *
+flat_bands (int bands, orc_fftmodel *fm, orc_fbmodel *bm)
+{
+  if (bands == ORC_FB_BANDS) {
+    orc_fbmodel_init (bm, 92.);
+    return &bm->b;
+  }
+  orc_fftmodel_init (fm, bands, 92.);
+  return &fm->b;
+}
+
+void
+orc_flat_fftear (int bands, double level_db, const float *x, int n_frames, int hop,
+                 double *power, double *weighted, double *unsmeared, double *excitation,
+                 int *energy, double *loudness)
+{
+  orc_fftmodel *m = (orc_fftmodel *) malloc (sizeof *m);
+  orc_fftstate st;
+  int f;
+  orc_fftmodel_init (m, bands, level_db);
+  orc_fftstate_reset (&st);
+  for (f = 0; f < n_frames; f++) {
+    orc_fftmodel_process (m, &st, x + (size_t) f * hop);
+    if (power) memcpy (power + (size_t) f * ORC_FFT_BINS, st.power, sizeof st.power);
+    if (weighted) memcpy (weighted + (size_t) f * ORC_FFT_BINS, st.weighted, sizeof st.weighted);
+    if (unsmeared) memcpy (unsmeared + (size_t) f * bands, st.unsmeared, bands * sizeof (double));
+    if (excitation) memcpy (excitation + (size_t) f * bands, st.excitation, bands * sizeof (double));
+    if (energy) energy[f] = st.energy_reached;
+    if (loudness) loudness[f] = orc_loudness (&m->b, st.excitation);
+  }
+  free (m);
+}
+
+void
+orc_flat_fbear (double level_db, const float *x, int n_blocks,
+                double *unsmeared, double *excitation, double *loudness)
+{
+  orc_fbmodel m;
+  orc_fbstate *st = (orc_fbstate *) malloc (sizeof *st);
+  int f;
+  orc_fbmodel_init (&m, level_db);
+  orc_fbstate_reset (st);
+  for (f = 0; f < n_blocks; f++) {
+    orc_fbmodel_process (&m, st, x + (size_t) f * ORC_FB_FRAME);
+    if (unsmeared) memcpy (unsmeared + (size_t) f * ORC_FB_BANDS, st->unsmeared, sizeof st->unsmeared);
+    if (excitation) memcpy (excitation + (size_t) f * ORC_FB_BANDS, st->excitation, sizeof st->excitation);
+    if (loudness) loudness[f] = orc_loudness (&m.b, st->excitation);
+  }
+  orc_fbmodel_free (&m);
+  free (st);
+}
+
+void
+orc_flat_leveladapt (int bands, const double *ref, const double *test, int n_calls,
+                     double *out_ref, double *out_test)
+{
+  orc_fftmodel *fm = (orc_fftmodel *) malloc (sizeof *fm);
+  orc_fbmodel bm;
+  const orc_bands *b = flat_bands (bands, fm, &bm);
+  orc_leveladapt l;
+  int f;
+  orc_leveladapt_reset (&l);
+  for (f = 0; f < n_calls; f++) {
+    orc_leveladapt_process (b, &l, ref + (size_t) f * bands, test + (size_t) f * bands);
+    memcpy (out_ref + (size_t) f * bands, l.adapted_ref, bands * sizeof (double));
+    memcpy (out_test + (size_t) f * bands, l.adapted_test, bands * sizeof (double));
+  }
+  if (bands == ORC_FB_BANDS)
+    orc_fbmodel_free (&bm);
+  free (fm);
+}
+
+void
+orc_flat_modproc (int bands, const double *in, int n_calls, double *out_mod, double *out_loud)
+{
+  orc_fftmodel *fm = (orc_fftmodel *) malloc (sizeof *fm);
+  orc_fbmodel bm;
+  const orc_bands *b = flat_bands (bands, fm, &bm);
+  orc_modproc m;
+  int f;
+  orc_modproc_reset (&m);
+  for (f = 0; f < n_calls; f++) {
+    orc_modproc_process (b, &m, in + (size_t) f * bands);
+    memcpy (out_mod + (size_t) f * bands, m.modulation, bands * sizeof (double));
+    memcpy (out_loud + (size_t) f * bands, m.filt_loud, bands * sizeof (double));
+  }
+  if (bands == ORC_FB_BANDS)
+    orc_fbmodel_free (&bm);
+  free (fm);
+}
+
+/* out: 8 rows of `bands` doubles: fc, internal_noise, ear_tc, exc_threshold,
+ * threshold, loud_factor, adapt_tc, mask_diff (zeros for the filter bank) */
+void
+orc_flat_tables (int bands, double *out)
+{
+  orc_fftmodel *fm = (orc_fftmodel *) malloc (sizeof *fm);
+  orc_fbmodel bm;
+  const orc_bands *b = flat_bands (bands, fm, &bm);
+  size_t n = bands * sizeof (double);
+  memcpy (out + 0 * bands, b->fc, n);
+  memcpy (out + 1 * bands, b->internal_noise, n);
+  memcpy (out + 2 * bands, b->ear_tc, n);
+  memcpy (out + 3 * bands, b->exc_threshold, n);
+  memcpy (out + 4 * bands, b->threshold, n);
+  memcpy (out + 5 * bands, b->loud_factor, n);
+  memcpy (out + 6 * bands, b->adapt_tc, n);
+  if (bands == ORC_FB_BANDS) {
+    memset (out + 7 * bands, 0, n);
+    orc_fbmodel_free (&bm);
+  } else {
+    memcpy (out + 7 * bands, fm->mask_diff, n);
+  }
+  free (fm);
+}

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REAL reference (oracle/_ref, built from
+/root/reference by oracle/Makefile).  Build-container only: /root/reference does
+not exist on the GPU box, the committed fixtures travel instead.
+
+  tests/golden/testpeaq_vectors.json  known answers held by the reference's own
+                                      unit test (src/testpeaq.c:37-599), as data
+  tests/golden/ref_e2e.json           MOVs / DI / ODG / totalsnr of the reference
+                                      element on tests/cases.py:e2e_cases()
+  tests/golden/ref_stages.npz         per-frame ear-model outputs (public getters)
+  tests/golden/ref_tables.json        band tables (Appendix C of SURVEY.md, in full)
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+import cases as case_defs  # noqa: E402
+
+REF = Path(os.environ.get("PEAQ_REFERENCE", "/root/reference"))
+GOLD = ROOT / "tests" / "golden"
+HARNESS = ROOT / "oracle" / "_ref" / "ref_harness"
+
+
+def _fix(v):
+    return [float("nan") if x == "nan" else float("inf") if x == "inf" else float("-inf") if x == "-inf" else x
+            for x in v]
+
+
+def run_harness(*args):
+    out = subprocess.run([str(HARNESS), *map(str, args)], check=True, capture_output=True, text=True).stdout
+    return json.loads(out)
+
+
+def extract_testpeaq():
+    src = (REF / "src" / "testpeaq.c").read_text()
+    out = {}
+    for m in re.finditer(r"static\s+(?:const\s+)?g?double\s+(\w+)\s*\[\s*\w*\s*\]\s*=\s*\{(.*?)\};", src, re.S):
+        name, body = m.group(1), m.group(2)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        vals = [float(t) for t in re.split(r"[,\s]+", body.strip()) if t]
+        out[name] = vals
+    expect = {"fft_ref_data": 1025, "weighted_fft_ref_data": 1025, "unsmeared_excitation_ref": 109,
+              "excitation_ref": 109, "modulation1_ref": 109, "modulation2_ref": 109,
+              "loudness1_ref": 109, "loudness2_ref": 109,
+              "spectrally_adapted_ref_patterns1_ref": 109, "spectrally_adapted_test_patterns1_ref": 109,
+              "spectrally_adapted_ref_patterns2_ref": 109, "spectrally_adapted_test_patterns2_ref": 109}
+    for k, n in expect.items():
+        assert len(out[k]) == n, (k, len(out.get(k, [])))
+    out["_tolerance"] = {"rel": 0.00005, "abs": 0.000005, "source": "testpeaq.c:33-35,606-621"}
+    (GOLD / "testpeaq_vectors.json").write_text(json.dumps(out))
+    print("testpeaq vectors:", {k: len(v) for k, v in out.items() if not k.startswith("_")})
+
+
+def e2e():
+    results = []
+    with tempfile.TemporaryDirectory() as td:
+        for case in case_defs.e2e_cases():
+            ref, test = case_defs.make_inputs(case)
+            rp, tp = Path(td) / "r.f32", Path(td) / "t.f32"
+            ref.astype("<f4").tofile(rp)
+            test.astype("<f4").tofile(tp)
+            r = run_harness("pair", case["advanced"], case["channels"], rp, tp)
+            if case["kind"] == "synth" and not any(case.get(k) for k in
+                                                   ("identical", "swap", "atten_shift", "ref_trim", "test_trim")):
+                # cross-check the numpy generator against the C header through the harness
+                r2 = run_harness("synth", case["advanced"], case["channels"], case["seed"], case["n"])
+                assert r2["movs"] == r["movs"], case["name"]
+            rec = dict(case=case, frames=r["frames"], fb_frames=r["fb_frames"],
+                       loudness_reached_frame=r["loudness_reached_frame"],
+                       movs=r["movs"], di=r["di"][0], odg=r["odg"][0], totalsnr=r["totalsnr"][0])
+            results.append(rec)
+            print(f"{case['name']:28s} adv={case['advanced']} frames={r['frames']:4d} odg={r['odg'][0]}")
+    (GOLD / "ref_e2e.json").write_text(json.dumps(results, indent=0))
+
+
+def stages():
+    arrays = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, x in case_defs.stage_inputs().items():
+            p = Path(td) / "x.f32"
+            x.astype("<f4").tofile(p)
+            for bands in (109, 55):
+                d = run_harness("fftear", bands, p)
+                for key in ("power", "weighted", "unsmeared", "excitation"):
+                    arrays[f"fft{bands}_{name}_{key}"] = np.array([_fix(f[key]) for f in d["frames"]])
+                arrays[f"fft{bands}_{name}_energy"] = np.array([f["energy"] for f in d["frames"]])
+                arrays[f"fft{bands}_{name}_loudness"] = np.array([f["loudness"] for f in d["frames"]])
+            d = run_harness("fbear", p)
+            for key in ("unsmeared", "excitation"):
+                arrays[f"fb_{name}_{key}"] = np.array([_fix(f[key]) for f in d["frames"]])
+            arrays[f"fb_{name}_loudness"] = np.array([f["loudness"] for f in d["frames"]])
+    np.savez_compressed(GOLD / "ref_stages.npz", **arrays)
+    print("stage arrays:", {k: v.shape for k, v in arrays.items()})
+
+
+def tables():
+    out = {}
+    for bands in (109, 55, 40):
+        out[str(bands)] = run_harness("tables", bands)
+    (GOLD / "ref_tables.json").write_text(json.dumps(out))
+
+
+def main():
+    subprocess.run(["make", "-C", str(ROOT / "oracle"), "ref"], check=True)
+    GOLD.mkdir(parents=True, exist_ok=True)
+    # the audiotestsrc transcription must match the real element bit for bit
+    with tempfile.TemporaryDirectory() as td:
+        env = dict(os.environ, PATH="/opt/conda/bin:" + os.environ["PATH"],
+                   GST_PLUGIN_SYSTEM_PATH="/opt/conda/lib/gstreamer-1.0",
+                   GST_PLUGIN_SCANNER="/opt/conda/libexec/gstreamer-1.0/gst-plugin-scanner",
+                   GST_REGISTRY="/tmp/peaq_ref_harness_registry.bin")
+        import synth_np
+        for wave in ("sine", "saw", "triangle"):
+            p = Path(td) / f"{wave}.f32"
+            subprocess.run(["gst-launch-1.0", "-q", "audiotestsrc", "num-buffers=16", f"wave={wave}", "freq=440",
+                            "!", "audio/x-raw,format=F32LE,rate=48000,channels=1", "!", "filesink",
+                            f"location={p}"], check=True, env=env)
+            x = np.fromfile(p, dtype="<f4")
+            assert np.array_equal(x, synth_np.audiotestsrc(wave, len(x))[:, 0]), wave
+    extract_testpeaq()
+    tables()
+    stages()
+    e2e()
+
+
+if __name__ == "__main__":
+    main()
