@@ -1,0 +1,218 @@
+"""ctypes binding of libpeaq_amd.so (include/peaq_amd.h)."""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+
+# gstpeaq.c:95-108 / :86-93
+MOV_NAMES_BASIC = ["BandwidthRefB", "BandwidthTestB", "TotalNMRB", "WinModDiff1B", "ADBB", "EHSB",
+                   "AvgModDiff1B", "AvgModDiff2B", "RmsNoiseLoudB", "MFPDB", "RelDistFramesB"]
+MOV_NAMES_ADVANCED = ["RmsModDiffA", "RmsNoiseLoudAsymA", "SegmentalNMRB", "EHSB", "AvgLinDistA"]
+
+RESULT_DOUBLES = 16
+RECORD_DOUBLES = 576
+
+
+class PeaqError(RuntimeError):
+    pass
+
+
+class _Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("frontend_ms", C.c_float), ("frontend_launches", C.c_int),
+                ("backend_ms", C.c_float), ("backend_launches", C.c_int),
+                ("fb_ms", C.c_float), ("fb_launches", C.c_int)]
+
+
+_LIB = None
+
+
+def library_path():
+    return PKG / "libpeaq_amd.so"
+
+
+def build_library(verbose=False):
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    env = dict(os.environ)
+    env.setdefault("HIPCC", "/opt/rocm/bin/hipcc")
+    r = subprocess.run(["make", "-C", str(PKG / "csrc"), "-j", "8"], env=env, capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode:
+        raise PeaqError("building libpeaq_amd.so failed")
+    return library_path()
+
+
+def load_library():
+    """Load libpeaq_amd.so; never falls back to anything else."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = library_path()
+    if not so.exists():
+        raise PeaqError(f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(the HIP extension is required, there is no CPU path)")
+    L = C.CDLL(str(so))
+    vp, dp, fp, u32p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    L.peaq_last_error.restype = C.c_char_p
+    L.peaq_version.restype = C.c_char_p
+    L.peaq_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.peaq_ctx_destroy.argtypes = [vp]
+    L.peaq_ctx_device.argtypes = [vp]
+    L.peaq_session_create.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.POINTER(vp)]
+    L.peaq_session_destroy.argtypes = [vp]
+    L.peaq_session_push.argtypes = [vp, C.c_int, fp, C.c_size_t]
+    L.peaq_session_flush.argtypes = [vp]
+    L.peaq_session_results.argtypes = [vp, dp]
+    L.peaq_session_reset.argtypes = [vp]
+    L.peaq_batch_run.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, C.c_size_t,
+                                 u32p, u32p, C.c_uint32, vp, vp]
+    L.peaq_batch_workspace_bytes.restype = C.c_size_t
+    L.peaq_batch_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32]
+    L.peaq_batch_last_timing.argtypes = [vp, C.POINTER(_Timing)]
+    L.peaq_synth_fill.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_size_t, vp, vp, vp]
+    L.peaq_debug_frontend.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp, vp, C.c_uint32, C.c_uint32,
+                                      C.c_int, dp]
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise PeaqError(f"libpeaq_amd error {rc}: {load_library().peaq_last_error().decode()}")
+
+
+def _result_dict(row, advanced):
+    n = 5 if advanced else 11
+    return dict(movs=np.array(row[:n]), di=float(row[11]), odg=float(row[12]), totalsnr=float(row[13]),
+                frames=int(row[14]), fb_blocks=int(row[15]))
+
+
+class Context:
+    """One per process and GPU: owns the constant tables in HBM."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        _check(self.L.peaq_ctx_create(int(device), C.byref(self.h)))
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.L.peaq_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_timing(self):
+        t = _Timing()
+        _check(self.L.peaq_batch_last_timing(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _Timing._fields_}
+
+
+class Session:
+    """Streaming session = one `peaq` element instance (host buffers in, results out)."""
+
+    def __init__(self, ctx, advanced, channels, playback_level=92.0):
+        self.ctx, self.advanced, self.channels = ctx, bool(advanced), channels
+        self.L = ctx.L
+        self.h = C.c_void_p()
+        _check(self.L.peaq_session_create(ctx.h, int(advanced), int(channels), float(playback_level),
+                                          C.byref(self.h)))
+
+    def push(self, pad, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        _check(self.L.peaq_session_push(self.h, int(pad), x.ctypes.data_as(C.POINTER(C.c_float)),
+                                        x.size // self.channels))
+
+    def push_ref(self, x):
+        self.push(0, x)
+
+    def push_test(self, x):
+        self.push(1, x)
+
+    def flush(self):
+        _check(self.L.peaq_session_flush(self.h))
+
+    def results(self):
+        out = np.zeros(RESULT_DOUBLES)
+        _check(self.L.peaq_session_results(self.h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return _result_dict(out, self.advanced)
+
+    def close(self):
+        if self.h:
+            self.L.peaq_session_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(int(stream))
+
+
+def batch_run(ctx, advanced, ref, test, n_ref=None, n_test=None, playback_level=92.0, results=None,
+              stream=None, sync=True):
+    """ref/test: CUDA float32 tensors [n_pairs, n_samples, channels] (contiguous).
+    n_ref/n_test: optional per-pair lengths (samples per channel).
+    Returns a list of result dicts (sync=True) or the device result tensor."""
+    import torch
+    assert ref.is_cuda and test.is_cuda and ref.dtype == torch.float32 and test.dtype == torch.float32
+    assert ref.is_contiguous() and test.is_contiguous() and ref.shape == test.shape and ref.dim() == 3
+    n_pairs, stride, channels = ref.shape
+    if results is None:
+        results = torch.empty((n_pairs, RESULT_DOUBLES), dtype=torch.float64, device=ref.device)
+    a_ref = a_test = None
+    if n_ref is not None:
+        a_ref = np.ascontiguousarray(n_ref, dtype=np.uint32)
+        a_test = np.ascontiguousarray(n_test, dtype=np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    _check(ctx.L.peaq_batch_run(ctx.h, int(bool(advanced)), channels, float(playback_level), n_pairs,
+                                C.c_void_p(ref.data_ptr()), C.c_void_p(test.data_ptr()), stride,
+                                a_ref.ctypes.data_as(u32p) if a_ref is not None else None,
+                                a_test.ctypes.data_as(u32p) if a_test is not None else None,
+                                stride, C.c_void_p(results.data_ptr()), _stream_ptr(stream)))
+    if not sync:
+        return results
+    torch.cuda.synchronize(ref.device)
+    rows = results.cpu().numpy()
+    return [_result_dict(r, advanced) for r in rows]
+
+
+def synth_fill(ctx, seed0, n_pairs, channels, n_samples, device="cuda:0", stream=None):
+    """-> (ref, test) CUDA tensors [n_pairs, n_samples, channels] of include/peaq_synth.h pairs"""
+    import torch
+    ref = torch.empty((n_pairs, n_samples, channels), dtype=torch.float32, device=device)
+    test = torch.empty_like(ref)
+    _check(ctx.L.peaq_synth_fill(ctx.h, int(seed0) & 0xFFFFFFFF, n_pairs, channels, n_samples, n_samples,
+                                 C.c_void_p(ref.data_ptr()), C.c_void_p(test.data_ptr()), _stream_ptr(stream)))
+    return ref, test
+
+
+def debug_frontend(ctx, bands, ref, test, n_frames, playback_level=92.0):
+    """Stage-level access: per-frame front-end records of ONE pair.
+    ref/test: CUDA float32 [n, channels] (may differ in length).  -> np [frames, channels, 576]"""
+    import torch
+    assert ref.is_cuda and test.is_cuda and ref.is_contiguous() and test.is_contiguous()
+    channels = ref.shape[1]
+    out = np.zeros((n_frames, channels, RECORD_DOUBLES))
+    torch.cuda.synchronize()
+    _check(ctx.L.peaq_debug_frontend(ctx.h, bands, channels, float(playback_level), C.c_void_p(ref.data_ptr()),
+                                     C.c_void_p(test.data_ptr()), ref.shape[0], test.shape[0], n_frames,
+                                     out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out

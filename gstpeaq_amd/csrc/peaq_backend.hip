@@ -1,0 +1,692 @@
+// peaq_backend.hip -- the stateful half of the PEAQ path: everything that
+// carries state from one frame to the next.  One workgroup per pair, one
+// wavefront per channel, frames processed in order; a lane owns two critical
+// bands (one for the 40-band filter bank) and keeps their recurrent state in
+// registers; lane i additionally owns MOV accumulator i of its channel.
+//
+// Reference functions restated here (file:line under /root/reference/src):
+//   time smearing                    fftearmodel.c:496-504
+//   level + pattern adaptation       leveladapter.c:243-340
+//   modulation patterns              modpatt.c:223-251
+//   loudness gate                    earmodel.c:891-907, gstpeaq.c:841-845
+//   modulation difference MOVs       movs.c:205-254
+//   noise loudness MOVs              movs.c:354-371, 551-577, 679-743
+//   NMR / relative disturbed frames  movs.c:1002-1022
+//   detection probability MOVs       movs.c:1224-1276
+//   accumulation + tentative logic   movaccum.c:317-425, gstpeaq.c:858-920, 965-1010
+//   read-out, DI, ODG                movaccum.c:438-481, nn.c:187-216,304-335,372-375
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "peaq_device.h"
+#include "peaq_kernels.h"
+#include "peaq_wave.h"
+
+namespace peaq {
+
+constexpr int kLdsBands = 128;      // 2 bands x 64 lanes: every lane may store, only valid bands are read
+
+// ---------------------------------------------------------------------------
+// MOV accumulator owned by one lane (movaccum.c)
+// ---------------------------------------------------------------------------
+struct LaneAcc {
+  double num, den, num2, p0, p1, p2, mx, filt, s_num, s_den, s_num2, s_mx;
+  int mode, status;
+
+  __device__ __forceinline__ void load(const double* f, int mode_, int status_) {
+    num = f[0]; den = f[1]; num2 = f[2]; p0 = f[3]; p1 = f[4]; p2 = f[5];
+    mx = f[6]; filt = f[7]; s_num = f[8]; s_den = f[9]; s_num2 = f[10]; s_mx = f[11];
+    mode = mode_;
+    status = status_;
+  }
+  __device__ __forceinline__ void store(double* f) const {
+    f[0] = num; f[1] = den; f[2] = num2; f[3] = p0; f[4] = p1; f[5] = p2;
+    f[6] = mx; f[7] = filt; f[8] = s_num; f[9] = s_den; f[10] = s_num2; f[11] = s_mx;
+  }
+  // movaccum.c:317-362
+  __device__ __forceinline__ void set_tentative(bool tentative) {
+    if (tentative) {
+      if (status == kNormal) {
+        s_num = num;
+        s_den = den;
+        s_num2 = num2;
+        s_mx = mx;                 // FILTERED_MAX: only `max`, not the filter state (:343-346)
+        status = kTentative;
+      }
+    } else {
+      status = kNormal;
+    }
+  }
+  // movaccum.c:368-425
+  __device__ __forceinline__ void add(double val, double w) {
+    if (status == kInit) return;
+    switch (mode) {
+      case kRms:
+        w *= w;
+        num += w * val * val;
+        den += w;
+        break;
+      case kRmsAsym:
+        num += val * val;
+        num2 += w * w;
+        den += 1.;
+        break;
+      case kAvg:
+      case kAvgLog:
+      case kAdb:
+        num += w * val;
+        den += w;
+        break;
+      case kAvgWindow: {
+        const double sq = sqrt(val);
+        if (!isnan(p0)) {
+          double ws = ((sq + p0) + p1) + p2;
+          ws /= 4.;
+          ws *= ws;
+          ws *= ws;
+          num += ws;
+          den += 1.;
+        }
+        p0 = p1;
+        p1 = p2;
+        p2 = sq;
+        break;
+      }
+      case kFilteredMax:
+        filt = 0.9 * filt + 0.1 * val;
+        if (filt > mx) mx = filt;
+        break;
+    }
+  }
+};
+
+__device__ __forceinline__ int acc_mode(bool advanced, int i) {
+  // gstpeaq.c:528-557
+  if (advanced) return i == 0 ? kRms : i == 1 ? kRmsAsym : kAvg;
+  switch (i) {
+    case 2: return kAvgLog;
+    case 3: return kAvgWindow;
+    case 4: return kAdb;
+    case 8: return kRms;
+    case 9: return kFilteredMax;
+    default: return kAvg;
+  }
+}
+
+// value of one channel's accumulator (movaccum.c:448-477, per-channel term)
+__device__ __forceinline__ double acc_channel_value(int mode, bool tentative, const double* f) {
+  const double num = tentative ? f[8] : f[0], den = tentative ? f[9] : f[1];
+  const double num2 = tentative ? f[10] : f[2], mx = tentative ? f[11] : f[6];
+  switch (mode) {
+    case kAvg: return num / den;
+    case kAvgLog: return 10. * log10(num / den);
+    case kAvgWindow:
+    case kRms: return sqrt(num / den);
+    case kRmsAsym: return sqrt(num / den) + 0.5 * sqrt(num2 / den);
+    case kFilteredMax: return mx;
+    case kAdb: return den > 0 ? (num == 0. ? -0.5 : log10(num / den)) : 0.;
+  }
+  return 0.;
+}
+
+// ---------------------------------------------------------------------------
+// shared per-frame building blocks; SLOTS bands per lane, band b = SLOTS*lane + s
+// ---------------------------------------------------------------------------
+template <int NB, int SLOTS>
+struct BandLane {
+  int lane;
+  __device__ __forceinline__ int band(int s) const { return SLOTS * lane + s; }
+  __device__ __forceinline__ bool valid(int s) const { return band(s) < NB; }
+};
+
+// leveladapter.c:243-340.  e_ref/e_test: excitation patterns of this frame.
+// st: [6][SLOTS] state (filt_ref, filt_test, num, den, pattcorr_ref, pattcorr_test)
+template <int NB, int SLOTS>
+__device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const BandTables* __restrict__ bt,
+                                            const double (&e_ref)[SLOTS], const double (&e_test)[SLOTS],
+                                            double (&st)[6][SLOTS], double* pa_lds /* [2][kLdsBands] */,
+                                            double (&ad_ref)[SLOTS], double (&ad_test)[SLOTS]) {
+  double num = 0., den = 0.;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    if (bl.valid(s)) {
+      const double a = bt->adapt_tc[bl.band(s)];
+      st[0][s] = a * st[0][s] + (1 - a) * e_ref[s];          // (42)/(43) in BS.1387
+      st[1][s] = a * st[1][s] + (1 - a) * e_test[s];
+      num += sqrt(st[0][s] * st[1][s]);                      // (45)
+      den += st[1][s];
+    }
+  }
+  num = wave_sum(num);
+  den = wave_sum(den);
+  const double lev = num * num / (den * den);
+  double lc_ref[SLOTS], lc_test[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    if (lev > 1) {                                           // (46)/(47)
+      lc_ref[s] = e_ref[s] / lev;
+      lc_test[s] = e_test[s];
+    } else {
+      lc_ref[s] = e_ref[s];
+      lc_test[s] = e_test[s] * lev;
+    }
+    double pr = 0., pt = 0.;
+    if (bl.valid(s)) {
+      const double a = bt->adapt_tc[bl.band(s)];
+      st[2][s] = a * st[2][s] + lc_test[s] * lc_ref[s];      // (48): no (1-a) gain, leveladapter.c:293-298
+      st[3][s] = a * st[3][s] + lc_ref[s] * lc_ref[s];
+      if (st[2][s] >= st[3][s]) {                            // (49)
+        pr = 1.;
+        pt = st[3][s] / st[2][s];
+      } else {
+        pr = st[2][s] / st[3][s];
+        pt = 1.;
+      }
+    }
+    pa_lds[bl.band(s)] = pr;
+    pa_lds[kLdsBands + bl.band(s)] = pt;
+  }
+  wave_lds_fence();
+  constexpr int M1 = NB / 36, M2 = NB / 25;                  // leveladapter.c:315-316
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    ad_ref[s] = 0.;
+    ad_test[s] = 0.;
+    if (bl.valid(s)) {
+      const int k = bl.band(s);
+      const int m1 = k < M1 ? k : M1;
+      const int m2 = (NB - k - 1) < M2 ? (NB - k - 1) : M2;
+      double rr = 0., rt = 0.;
+      for (int l = k - m1; l <= k + m2; ++l) {               // (50)/(51)
+        rr += pa_lds[l];
+        rt += pa_lds[kLdsBands + l];
+      }
+      rr /= (m1 + m2 + 1);
+      rt /= (m1 + m2 + 1);
+      const double a = bt->adapt_tc[k];
+      st[4][s] = a * st[4][s] + (1 - a) * rr;
+      st[5][s] = a * st[5][s] + (1 - a) * rt;
+      ad_ref[s] = lc_ref[s] * st[4][s];                      // (52)/(53)
+      ad_test[s] = lc_test[s] * st[5][s];
+    }
+  }
+  wave_lds_fence();
+}
+
+// modpatt.c:223-251; st: prev_loud, filt_loud, filt_dloud
+template <int NB, int SLOTS>
+__device__ __forceinline__ void modulation(const BandLane<NB, SLOTS>& bl, const BandTables* __restrict__ bt,
+                                           const double (&loud)[SLOTS], double (&st)[3][SLOTS],
+                                           double (&mod)[SLOTS]) {
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    mod[s] = 0.;
+    if (bl.valid(s)) {
+      const double a = bt->adapt_tc[bl.band(s)];
+      const double dl = bt->deriv_factor * fabs(loud[s] - st[0][s]);
+      st[2][s] = a * st[2][s] + (1 - a) * dl;
+      st[1][s] = a * st[1][s] + (1. - a) * loud[s];
+      mod[s] = st[2][s] / (1. + st[1][s] / 0.3);
+      st[0][s] = loud[s];
+    }
+  }
+}
+
+// earmodel.c:891-907
+template <int NB, int SLOTS>
+__device__ __forceinline__ double total_loudness(const BandLane<NB, SLOTS>& bl, const BandTables* __restrict__ bt,
+                                                 const double (&exc)[SLOTS]) {
+  double t = 0.;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    if (bl.valid(s)) {
+      const int b = bl.band(s);
+      const double thr = bt->threshold[b];
+      const double l = bt->loud_factor[b] * (pow(1. - thr + thr * exc[s] / bt->exc_threshold[b], 0.23) - 1.);
+      t += fmax(l, 0.);
+    }
+  }
+  return wave_sum(t) * (24. / NB);
+}
+
+// movs.c:709-743
+template <int NB, int SLOTS>
+__device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, const BandTables* __restrict__ bt,
+                                                 double alpha, double thres_fac, double s0, double nl_min,
+                                                 const double (&mod_ref)[SLOTS], const double (&mod_test)[SLOTS],
+                                                 const double (&e_ref)[SLOTS], const double (&e_test)[SLOTS]) {
+  double nl = 0.;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    if (bl.valid(s)) {
+      const double sref = thres_fac * mod_ref[s] + s0;
+      const double stest = thres_fac * mod_test[s] + s0;
+      const double ethres = bt->internal_noise[bl.band(s)];
+      const double beta = exp(-alpha * (e_test[s] - e_ref[s]) / e_ref[s]);
+      nl += pow(ethres / stest, 0.23) *
+            (pow(1. + fmax(stest * e_test[s] - sref * e_ref[s], 0.) / (ethres + sref * e_ref[s] * beta), 0.23) - 1.);
+    }
+  }
+  nl = wave_sum(nl) * (24. / NB);
+  return nl < nl_min ? 0. : nl;
+}
+
+// movs.c:224-251: returns d1 (un-normalised), d2, weight
+template <int NB, int SLOTS>
+__device__ __forceinline__ void mod_difference(const BandLane<NB, SLOTS>& bl, const BandTables* __restrict__ bt,
+                                               double lev_wt, const double (&mr)[SLOTS], const double (&mt)[SLOTS],
+                                               const double (&loud_ref)[SLOTS], double& d1, double& d2, double& wt) {
+  double a1 = 0., a2 = 0., aw = 0.;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    if (bl.valid(s)) {
+      const double diff = fabs(mr[s] - mt[s]);
+      a1 += diff / (1. + mr[s]);
+      a2 += (mt[s] >= mr[s] ? 1. : .1) * diff / (0.01 + mr[s]);
+      aw += loud_ref[s] / (loud_ref[s] + lev_wt * bt->noise_pow03[bl.band(s)]);
+    }
+  }
+  d1 = wave_sum(a1);
+  d2 = wave_sum(a2);
+  wt = wave_sum(aw);
+}
+
+// ---------------------------------------------------------------------------
+// FFT-model back end.  ADV = false: basic version (109 bands, 11 MOVs).
+// ADV = true: the FFT part of the advanced version (55 bands; SegmentalNMR, EHS).
+// ---------------------------------------------------------------------------
+enum { MB_BW_REF, MB_BW_TEST, MB_NMR, MB_WINMOD, MB_ADB, MB_EHS, MB_AVGMOD1, MB_AVGMOD2, MB_NOISELOUD, MB_MFPD,
+       MB_RELDIST };                                         // gstpeaq.c:95-108
+enum { MA_RMSMOD, MA_NLASYM, MA_SEGNMR, MA_EHS, MA_LINDIST };   // gstpeaq.c:86-93
+
+struct BackendShared {
+  double pa[2][2][kLdsBands];       // [wave][ref/test][band] pattern-adaptation ratios
+  double pc[2][kLdsBands];          // detection probabilities per channel
+  double qc[2][kLdsBands];
+  double acc_val[2][kMaxAcc];
+  double acc_w[2][kMaxAcc];
+  int acc_mask[2];
+  int gate[2];
+};
+
+template <int NB, bool ADV>
+__global__ __launch_bounds__(128) void backend_kernel(BackendArgs a) {
+  __shared__ BackendShared sh;
+  constexpr int SLOTS = 2;
+  const int lane = threadIdx.x & 63;
+  const int chan = threadIdx.x >> 6;
+  const int channels = a.channels;                  // == blockDim.x / 64
+  const unsigned pair = blockIdx.x;
+  const BandTables* __restrict__ bt = a.bands;
+  const BandLane<NB, SLOTS> bl{lane};
+  PairState* __restrict__ ps = a.state + pair;
+  ChannelState* __restrict__ cs = &ps->ch[chan];
+
+  const unsigned n_frames = a.n_frames ? a.n_frames[pair] : a.n_frames_uniform;
+  unsigned f_end = a.frame0 + a.frames_per_launch;
+  if (f_end > n_frames) f_end = n_frames;
+  if (a.frame0 >= f_end) return;
+
+  // ---- recurrent state -> registers -----------------------------------------------
+  double sm[2][SLOTS];                               // smeared excitation filters (ref, test)
+  double la[6][SLOTS];
+  double mdr[3][SLOTS], mdt[3][SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int b = bl.band(s);
+    sm[0][s] = cs->vec[kSmearRef][b < kBandStride ? b : 0];
+    sm[1][s] = cs->vec[kSmearTest][b < kBandStride ? b : 0];
+#pragma unroll
+    for (int v = 0; v < 6; ++v) la[v][s] = cs->vec[kLaFiltRef + v][b < kBandStride ? b : 0];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      mdr[v][s] = cs->vec[kModPrevRef + v][b < kBandStride ? b : 0];
+      mdt[v][s] = cs->vec[kModPrevTest + v][b < kBandStride ? b : 0];
+    }
+  }
+  LaneAcc acc;
+  {
+    const int i = lane < kMaxAcc ? lane : 0;
+    acc.load(cs->acc[i], acc_mode(ADV, i), ps->status[i]);
+  }
+  unsigned loud_reached = ps->loudness_reached;
+  double sig_e = ps->sig_energy, noise_e = ps->noise_energy;
+
+  for (unsigned frame = a.frame0; frame < f_end; ++frame) {
+    const double* __restrict__ rec0 =
+        a.records + ((size_t)(pair * a.frames_per_launch + (frame - a.frame0)) * channels) * kRecDoubles;
+    const double* __restrict__ rec = rec0 + (size_t)chan * kRecDoubles;
+
+    // ---- frame flags over all channels (gstpeaq.c:858-862, movs.c:1374-1381) -----
+    int fl_ref = (int)rec0[kRecFlagsRef], fl_test = (int)rec0[kRecFlagsTest];
+    if (channels == 2) {
+      fl_ref |= (int)rec0[kRecDoubles + kRecFlagsRef];
+      fl_test |= (int)rec0[kRecDoubles + kRecFlagsTest];
+    }
+    const bool above = fl_ref & 1;
+    const bool ehs_valid = ((fl_ref | fl_test) & 2) != 0;
+    if (!ADV || lane == MA_SEGNMR || lane == MA_EHS) acc.set_tentative(!above);
+
+    // ---- this frame's patterns -------------------------------------------------------
+    double ur[SLOTS], ut[SLOTS], lr[SLOTS], lt[SLOTS], nz[SLOTS];
+    {
+      const int b0 = bl.band(0);
+      const int bb = b0 < kBandStride ? b0 : 0;
+      const double2 v0 = *reinterpret_cast<const double2*>(rec + kRecUnsmRef + bb);
+      const double2 v1 = *reinterpret_cast<const double2*>(rec + kRecUnsmTest + bb);
+      const double2 v2 = *reinterpret_cast<const double2*>(rec + kRecLoudRef + bb);
+      const double2 v3 = *reinterpret_cast<const double2*>(rec + kRecLoudTest + bb);
+      const double2 v4 = *reinterpret_cast<const double2*>(rec + kRecNoise + bb);
+      ur[0] = v0.x; ur[1] = v0.y; ut[0] = v1.x; ut[1] = v1.y;
+      lr[0] = v2.x; lr[1] = v2.y; lt[0] = v3.x; lt[1] = v3.y;
+      nz[0] = v4.x; nz[1] = v4.y;
+    }
+    // time smearing, fftearmodel.c:496-504
+    double er[SLOTS], et[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int b = bl.band(s) < kBandStride ? bl.band(s) : 0;
+      const double ac = bt->ear_tc[b];
+      sm[0][s] = ac * sm[0][s] + (1. - ac) * ur[s];
+      er[s] = sm[0][s] > ur[s] ? sm[0][s] : ur[s];
+      if (!ADV) {
+        sm[1][s] = ac * sm[1][s] + (1. - ac) * ut[s];
+        et[s] = sm[1][s] > ut[s] ? sm[1][s] : ut[s];
+      } else {
+        et[s] = 0.;
+      }
+    }
+
+    double v_val[kMaxAcc], v_w[kMaxAcc];
+    int mask = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxAcc; ++i) {
+      v_val[i] = 0.;
+      v_w[i] = 1.;
+    }
+
+    if (!ADV) {
+      // ---- pattern processing (gstpeaq.c:834-845) ------------------------------------
+      double ad_ref[SLOTS], ad_test[SLOTS], mr[SLOTS], mt[SLOTS];
+      level_adapt<NB, SLOTS>(bl, bt, er, et, la, &sh.pa[chan][0][0], ad_ref, ad_test);
+      modulation<NB, SLOTS>(bl, bt, lr, mdr, mr);
+      modulation<NB, SLOTS>(bl, bt, lt, mdt, mt);
+      if (loud_reached == UINT_MAX) {                // wave-uniform
+        const double n_ref = total_loudness<NB, SLOTS>(bl, bt, er);
+        const double n_test = total_loudness<NB, SLOTS>(bl, bt, et);
+        if (lane == 0) sh.gate[chan] = (n_ref > 0.1 && n_test > 0.1);
+      }
+      // ---- detection probability, per channel part (movs.c:1239-1262) -----------------
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        double pc = 0., qc = 0.;
+        if (bl.valid(s)) {
+          const double er_db = 10. * log10(er[s]);
+          const double et_db = 10. * log10(et[s]);
+          const double l = 0.3 * fmax(er_db, et_db) + 0.7 * et_db;
+          const double l2 = l * l;
+          const double sd = l > 0. ? 5.95072 * pow(6.39468 / l, 1.71332) + 9.01033e-11 * l2 * l2 +
+                                         5.05622e-6 * l2 * l - 0.00102438 * l * l + 0.0550197 * l - 0.198719
+                                   : 1e30;
+          const double e = er_db - et_db;
+          const double x = e / sd, x2 = x * x;
+          const double xb = er_db > et_db ? x2 * x2 : x2 * x2 * x2;   // (e/s)^b, b = 4 or 6
+          pc = 1. - exp2(-xb);                                        // 1 - 0.5^((e/s)^b)
+          qc = fabs(trunc(e)) / sd;
+        }
+        sh.pc[chan][bl.band(s)] = pc;
+        sh.qc[chan][bl.band(s)] = qc;
+      }
+      __syncthreads();
+      if (loud_reached == UINT_MAX) {
+        const int g = sh.gate[0] | (channels == 2 ? sh.gate[1] : 0);
+        if (g) loud_reached = frame;
+      }
+      // ---- modulation difference (gstpeaq.c:871-877) --------------------------------
+      if (frame >= 24) {
+        double d1, d2, wt;
+        mod_difference<NB, SLOTS>(bl, bt, 100., mr, mt, mdr[1], d1, d2, wt);
+        d1 *= 100. / NB;
+        d2 *= 100. / NB;
+        v_val[MB_AVGMOD1] = d1; v_w[MB_AVGMOD1] = wt;
+        v_val[MB_AVGMOD2] = d2; v_w[MB_AVGMOD2] = wt;
+        v_val[MB_WINMOD] = d1;
+        mask |= (1 << MB_AVGMOD1) | (1 << MB_AVGMOD2) | (1 << MB_WINMOD);
+      }
+      // ---- noise loudness (gstpeaq.c:880-886; unsigned compare with UINT_MAX sentinel)
+      if (frame >= 24 && frame - 3 >= loud_reached) {
+        v_val[MB_NOISELOUD] = noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 0.5, 0., mr, mt, ad_ref, ad_test);
+        mask |= 1 << MB_NOISELOUD;
+      }
+      // ---- bandwidth (movs.c:797-807) ------------------------------------------------------
+      {
+        const double bw_ref = rec[kRecBwRef];
+        if (bw_ref > 346.) {
+          v_val[MB_BW_REF] = bw_ref;
+          v_val[MB_BW_TEST] = rec[kRecBwTest];
+          mask |= (1 << MB_BW_REF) | (1 << MB_BW_TEST);
+        }
+      }
+    }
+    // ---- noise-to-mask ratio (movs.c:1002-1022) ---------------------------------------
+    {
+      double nsum = 0., nmax = 0.;
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        if (bl.valid(s)) {
+          const double m = er[s] / bt->mask_diff[bl.band(s)];
+          const double r = nz[s] / m;
+          nsum += r;
+          if (r > nmax) nmax = r;
+        }
+      }
+      nsum = wave_sum(nsum) / NB;
+      nmax = wave_max(nmax);
+      if (!ADV) {
+        v_val[MB_NMR] = nsum;                                       // MODE_AVG_LOG
+        v_val[MB_RELDIST] = nmax > 1.41253754462275 ? 1. : 0.;
+        mask |= (1 << MB_NMR) | (1 << MB_RELDIST);
+      } else {
+        v_val[MA_SEGNMR] = 10. * log10(nsum);                       // MODE_AVG
+        mask |= 1 << MA_SEGNMR;
+      }
+    }
+    // ---- error harmonic structure (movs.c:1374-1381,1442) ------------------------------
+    if (ehs_valid) {
+      v_val[ADV ? MA_EHS : MB_EHS] = 1000. * rec[kRecEhs];
+      mask |= 1 << (ADV ? MA_EHS : MB_EHS);
+    }
+    // ---- detection probability, binaural part (movs.c:1263-1275) --------------------------
+    if (!ADV && chan == 0) {
+      double pprod = 1., qsum = 0.;
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        if (bl.valid(s)) {
+          const int b = bl.band(s);
+          double p = 0., q = sh.qc[0][b];
+          if (sh.pc[0][b] > p) p = sh.pc[0][b];
+          if (channels == 2) {
+            if (sh.pc[1][b] > p) p = sh.pc[1][b];
+            if (sh.qc[1][b] > q) q = sh.qc[1][b];
+          }
+          pprod *= 1. - p;
+          qsum += q;
+        }
+      }
+      const double p_bin = 1. - wave_prod(pprod);
+      qsum = wave_sum(qsum);
+      if (p_bin > 0.5) {
+        v_val[MB_ADB] = qsum;
+        mask |= 1 << MB_ADB;
+      }
+      v_val[MB_MFPD] = p_bin;
+      mask |= 1 << MB_MFPD;
+    }
+    // ---- totalsnr (gstpeaq.c:913-918) --------------------------------------------------------
+    if (chan == 0) {
+      sig_e += rec0[kRecSigE] + (channels == 2 ? rec0[kRecDoubles + kRecSigE] : 0.);
+      noise_e += rec0[kRecNoiseE] + (channels == 2 ? rec0[kRecDoubles + kRecNoiseE] : 0.);
+    }
+    // ---- accumulate: lane i owns accumulator i --------------------------------------------------
+    {
+      double my_v = 0., my_w = 1.;
+#pragma unroll
+      for (int i = 0; i < kMaxAcc; ++i) {
+        if (lane == i) {
+          my_v = v_val[i];
+          my_w = v_w[i];
+        }
+      }
+      if (lane < kMaxAcc && ((mask >> lane) & 1)) acc.add(my_v, my_w);
+    }
+    if (!ADV) __syncthreads();                       // sh.pc/qc/gate are rewritten next frame
+  }
+
+  // ---- registers -> recurrent state -------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int b = bl.band(s);
+    if (b < kBandStride) {
+      cs->vec[kSmearRef][b] = sm[0][s];
+      cs->vec[kSmearTest][b] = sm[1][s];
+      if (!ADV) {                                    // advanced: these belong to the filter-bank back end
+#pragma unroll
+        for (int v = 0; v < 6; ++v) cs->vec[kLaFiltRef + v][b] = la[v][s];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          cs->vec[kModPrevRef + v][b] = mdr[v][s];
+          cs->vec[kModPrevTest + v][b] = mdt[v][s];
+        }
+      }
+    }
+  }
+  if (lane < kMaxAcc) {
+    if (!ADV || lane == MA_SEGNMR || lane == MA_EHS) {
+      acc.store(cs->acc[lane]);
+      if (chan == 0) ps->status[lane] = acc.status;
+    }
+  }
+  if (chan == 0 && lane == 0) {
+    ps->frame_counter = f_end;
+    if (!ADV) ps->loudness_reached = loud_reached;
+    ps->sig_energy = sig_e;
+    ps->noise_energy = noise_e;
+  }
+}
+
+hipError_t launch_backend(const BackendArgs& a, unsigned n_pairs, hipStream_t stream) {
+  if (n_pairs == 0) return hipSuccess;
+  const dim3 block(64 * a.channels);
+  if (!a.advanced)
+    hipLaunchKernelGGL((backend_kernel<109, false>), dim3(n_pairs), block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((backend_kernel<55, true>), dim3(n_pairs), block, 0, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// state initialisation (gstpeaq.c:357-361, movaccum.c:276-299, *_state_alloc: zeros)
+// ---------------------------------------------------------------------------
+__global__ void state_init_kernel(PairState* st, unsigned n_pairs) {
+  const unsigned pair = blockIdx.x;
+  if (pair >= n_pairs) return;
+  PairState* ps = st + pair;
+  double* raw = reinterpret_cast<double*>(ps);
+  for (unsigned i = threadIdx.x; i < sizeof(PairState) / sizeof(double); i += blockDim.x) raw[i] = 0.;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ps->loudness_reached = UINT_MAX;
+    for (int i = 0; i < kMaxAcc; ++i) ps->status[i] = kInit;
+    for (int c = 0; c < 2; ++c)
+      for (int i = 0; i < kMaxAcc; ++i) {
+        // AVG_WINDOW history starts as NaN sentinels (movaccum.c:293)
+        ps->ch[c].acc[i][3] = ps->ch[c].acc[i][4] = ps->ch[c].acc[i][5] = __builtin_nan("");
+      }
+  }
+}
+
+hipError_t launch_state_init(PairState* state, int /*advanced*/, unsigned n_pairs, hipStream_t stream) {
+  if (n_pairs == 0) return hipSuccess;
+  hipLaunchKernelGGL(state_init_kernel, dim3(n_pairs), dim3(256), 0, stream, state, n_pairs);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// read-out: one thread per pair (movaccum.c:438-481, gstpeaq.c:1013-1078, nn.c)
+// ---------------------------------------------------------------------------
+__constant__ double nb_amin[11] = {393.916656, 361.965332, -24.045116, 1.110661, -0.206623, 0.074318,
+                                   1.113683, 0.950345, 0.029985, 0.000101, 0.};
+__constant__ double nb_amax[11] = {921, 881.131226, 16.212030, 107.137772, 2.886017, 13.933351,
+                                   63.257874, 1145.018555, 14.819740, 1., 1.};
+__constant__ double nb_wx[11][3] = {{-0.502657, 0.436333, 1.219602},  {4.307481, 3.246017, 1.123743},
+                                    {4.984241, -2.211189, -0.192096}, {0.051056, -1.762424, 4.331315},
+                                    {2.321580, 1.789971, -0.754560},  {-5.303901, -3.452257, -10.814982},
+                                    {2.730991, -6.111805, 1.519223},  {0.624950, -1.331523, -5.955151},
+                                    {3.102889, 0.871260, -5.922878},  {-1.051468, -0.939882, -0.142913},
+                                    {-1.804679, -0.503610, -0.620456}};
+__constant__ double nb_wxb[3] = {-2.518254, 0.654841, -2.207228};
+__constant__ double nb_wy[3] = {-3.817048, 4.107138, 4.629582};
+__constant__ double na_amin[5] = {13.298751, 0.041073, -25.018791, 0.061560, 0.02452};
+__constant__ double na_amax[5] = {2166.5, 13.24326, 13.46708, 10.226771, 14.224874};
+__constant__ double na_wx[5][5] = {{21.211773, -39.013052, -1.382553, -14.545348, -0.320899},
+                                   {-8.981803, 19.956049, 0.935389, -1.686586, -3.238586},
+                                   {1.633830, -2.877505, -7.442935, 5.606502, -1.783120},
+                                   {6.103821, 19.587435, -0.240284, 1.088213, -0.511314},
+                                   {11.556344, 3.892028, 9.720441, -3.287205, -11.031250}};
+__constant__ double na_wxb[5] = {1.330890, 2.686103, 2.096598, -1.327851, 3.087055};
+__constant__ double na_wy[5] = {-4.696996, -3.289959, 7.004782, 6.651897, 4.009144};
+
+__global__ void finalize_kernel(const PairState* __restrict__ st, int advanced, int channels, unsigned n_pairs,
+                                ResultRecord* __restrict__ out) {
+  const unsigned pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= n_pairs) return;
+  const PairState* ps = st + pair;
+  ResultRecord r;
+  const int n_movs = advanced ? 5 : 11;
+  for (int i = 0; i < 11; ++i) r.movs[i] = 0.;
+  for (int i = 0; i < n_movs; ++i) {
+    const int mode = acc_mode(advanced, i);
+    // basic: ADB and MFPD have ONE channel (gstpeaq.c:580-584)
+    const int nch = (!advanced && (i == MB_ADB || i == MB_MFPD)) ? 1 : channels;
+    const bool tent = ps->status[i] == kTentative;
+    double v = 0.;
+    for (int c = 0; c < nch; ++c) v += acc_channel_value(mode, tent, ps->ch[c].acc[i]);
+    r.movs[i] = v / nch;
+  }
+  double di;
+  if (!advanced) {
+    double x[3] = {nb_wxb[0], nb_wxb[1], nb_wxb[2]};
+    for (int i = 0; i < 11; ++i) {
+      const double m = (r.movs[i] - nb_amin[i]) / (nb_amax[i] - nb_amin[i]);   // CLAMP_MOVS 0
+      for (int j = 0; j < 3; ++j) x[j] += nb_wx[i][j] * m;
+    }
+    di = -0.307594;
+    for (int j = 0; j < 3; ++j) di += nb_wy[j] / (1 + exp(-x[j]));
+  } else {
+    double x[5];
+    for (int j = 0; j < 5; ++j) x[j] = na_wxb[j];
+    for (int i = 0; i < 5; ++i) {
+      const double m = (r.movs[i] - na_amin[i]) / (na_amax[i] - na_amin[i]);
+      for (int j = 0; j < 5; ++j) x[j] += na_wx[i][j] * m;
+    }
+    di = -1.360308;
+    for (int j = 0; j < 5; ++j) di += na_wy[j] / (1 + exp(-x[j]));
+  }
+  r.di = di;
+  r.odg = -3.98 + (0.22 - -3.98) / (1 + exp(-di));          // nn.c:92-93,372-375
+  r.totalsnr = 10 * log10(ps->sig_energy / ps->noise_energy);
+  r.frames = (double)ps->frame_counter;
+  r.fb_blocks = (double)ps->fb_counter;
+  out[pair] = r;
+}
+
+hipError_t launch_finalize(const PairState* state, int advanced, int channels, unsigned n_pairs, ResultRecord* out,
+                           hipStream_t stream) {
+  if (n_pairs == 0) return hipSuccess;
+  hipLaunchKernelGGL(finalize_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, stream, state, advanced, channels,
+                     n_pairs, out);
+  return hipGetLastError();
+}
+
+}  // namespace peaq

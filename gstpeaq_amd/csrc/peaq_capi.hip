@@ -1,0 +1,624 @@
+// peaq_capi.hip -- the C ABI of include/peaq_amd.h: device context, batch
+// driver, streaming sessions.  Host code only; the kernels are in
+// peaq_frontend.hip / peaq_backend.hip / peaq_fb.hip / peaq_synth.hip.
+//
+// Framing follows the reference element: FFT frames of 2048 samples every 1024
+// (do_processing, gstpeaq.c:596-611), filter-bank blocks of 192 every 192, and
+// at the end ONE zero-padded frame/block built from whatever is left on either
+// side (do_flush, gstpeaq.c:716-745).  Frame f of a pair reads samples
+// [1024 f, 1024 f + 2048) of each signal, zero beyond the signal's length.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/peaq_amd.h"
+#include "peaq_device.h"
+#include "peaq_kernels.h"
+#include "peaq_tables.h"
+
+using namespace peaq;
+
+static_assert(sizeof(ResultRecord) == sizeof(peaq_result), "result layouts must match");
+static_assert(kRecDoubles == PEAQ_DEBUG_RECORD_DOUBLES, "record layouts must match");
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                                     \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess)                                                                                 \
+      return fail(e_ == hipErrorOutOfMemory ? PEAQ_ERR_NOMEM : PEAQ_ERR_DEVICE,                           \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                     \
+  } while (0)
+
+extern "C" const char* peaq_last_error(void) { return g_err.c_str(); }
+extern "C" const char* peaq_version(void) { return "0.1.0 gfx950"; }
+
+// ---------------------------------------------------------------------------
+// framing arithmetic
+// ---------------------------------------------------------------------------
+// number of frames the element processes for signals of n_ref / n_test samples:
+// full frames while BOTH adapters hold `frame` samples, then one flush frame if
+// anything is left on either side.
+static uint32_t count_frames(uint64_t n_ref, uint64_t n_test, uint32_t frame, uint32_t hop) {
+  const uint64_t n = std::min(n_ref, n_test);
+  const uint64_t full = n >= frame ? (n - frame) / hop + 1 : 0;
+  const bool left = n_ref > full * hop || n_test > full * hop;
+  return static_cast<uint32_t>(full + (left ? 1 : 0));
+}
+
+// ---------------------------------------------------------------------------
+// growable device buffer
+// ---------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct TimedSpan {
+  hipEvent_t a, b;
+  int kind;   // 0 front end, 1 back end, 2 filter bank
+};
+
+struct peaq_ctx {
+  int device = 0;
+  CommonTables* d_common = nullptr;
+  BandTables* d_bands109 = nullptr;
+  BandTables* d_bands55 = nullptr;
+  BandTables* d_bands40 = nullptr;
+  FbTables* d_fb = nullptr;
+  std::mutex mu;            // serialises batch calls / workspace use
+  // batch workspace
+  DevBuf records, fb_records, state, fbstate, hp_scratch, counts;
+  hipEvent_t batch_begin = nullptr, batch_end = nullptr;
+  bool batch_pending = false;
+  std::vector<TimedSpan> spans;
+  std::vector<hipEvent_t> event_pool;
+  size_t events_used = 0;
+
+  hipEvent_t next_event() {
+    if (events_used == event_pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      event_pool.push_back(e);
+    }
+    return event_pool[events_used++];
+  }
+};
+
+extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
+  if (!out) return fail(PEAQ_ERR_ARG, "peaq_ctx_create: out is NULL");
+  *out = nullptr;
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev == 0)
+    return fail(PEAQ_ERR_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e));
+  if (device < 0 || device >= n_dev) return fail(PEAQ_ERR_ARG, "peaq_ctx_create: bad device ordinal");
+  HIP_TRY(hipSetDevice(device));
+  peaq_ctx* c = new (std::nothrow) peaq_ctx;
+  if (!c) return fail(PEAQ_ERR_NOMEM, "out of host memory");
+  c->device = device;
+  {
+    std::vector<CommonTables> h(1);
+    build_common_tables(h[0]);
+    HIP_TRY(hipMalloc(&c->d_common, sizeof(CommonTables)));
+    HIP_TRY(hipMemcpy(c->d_common, h.data(), sizeof(CommonTables), hipMemcpyHostToDevice));
+  }
+  {
+    BandTables t;
+    build_fft_band_tables(109, t);
+    HIP_TRY(hipMalloc(&c->d_bands109, sizeof t));
+    HIP_TRY(hipMemcpy(c->d_bands109, &t, sizeof t, hipMemcpyHostToDevice));
+    build_fft_band_tables(55, t);
+    HIP_TRY(hipMalloc(&c->d_bands55, sizeof t));
+    HIP_TRY(hipMemcpy(c->d_bands55, &t, sizeof t, hipMemcpyHostToDevice));
+    std::vector<FbTables> fb(1);
+    build_fb_band_tables(t, fb[0]);
+    HIP_TRY(hipMalloc(&c->d_bands40, sizeof t));
+    HIP_TRY(hipMemcpy(c->d_bands40, &t, sizeof t, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&c->d_fb, sizeof(FbTables)));
+    HIP_TRY(hipMemcpy(c->d_fb, fb.data(), sizeof(FbTables), hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipEventCreate(&c->batch_begin));
+  HIP_TRY(hipEventCreate(&c->batch_end));
+  *out = c;
+  return PEAQ_OK;
+}
+
+extern "C" void peaq_ctx_destroy(peaq_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(c->d_common);
+  (void)hipFree(c->d_bands109);
+  (void)hipFree(c->d_bands55);
+  (void)hipFree(c->d_bands40);
+  (void)hipFree(c->d_fb);
+  c->records.release();
+  c->fb_records.release();
+  c->state.release();
+  c->fbstate.release();
+  c->hp_scratch.release();
+  c->counts.release();
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+  if (c->batch_begin) (void)hipEventDestroy(c->batch_begin);
+  if (c->batch_end) (void)hipEventDestroy(c->batch_end);
+  delete c;
+}
+
+extern "C" int peaq_ctx_device(const peaq_ctx* c) { return c ? c->device : -1; }
+
+// ---------------------------------------------------------------------------
+// batch
+// ---------------------------------------------------------------------------
+static const size_t kRecordBudget = (size_t)1536 << 20;   // HBM for per-frame records of one chunk
+
+static unsigned frames_per_chunk(int n_pairs, int channels, uint32_t max_frames) {
+  const size_t per_frame = (size_t)n_pairs * channels * kRecDoubles * sizeof(double);
+  size_t fc = kRecordBudget / std::max<size_t>(per_frame, 1);
+  fc = std::max<size_t>(fc, 4);
+  fc = std::min<size_t>(fc, 64);
+  // few pairs: take long chunks so that the launch count stays small
+  if ((size_t)max_frames * per_frame <= ((size_t)256 << 20)) fc = max_frames;
+  return static_cast<unsigned>(std::min<size_t>(fc, std::max<uint32_t>(max_frames, 1)));
+}
+
+extern "C" size_t peaq_batch_workspace_bytes(int advanced, int channels, int n_pairs, uint32_t n_max) {
+  const uint32_t frames = count_frames(n_max, n_max, kFrame, kHop);
+  const unsigned fc = frames_per_chunk(n_pairs, channels, frames);
+  size_t b = (size_t)n_pairs * fc * channels * kRecDoubles * sizeof(double) + (size_t)n_pairs * sizeof(PairState) +
+             (size_t)n_pairs * 4 * sizeof(uint32_t);
+  if (advanced) {
+    const unsigned bc = fc * 6;
+    b += (size_t)n_pairs * bc * channels * kFbRecDoubles * sizeof(double);
+    b += (size_t)n_pairs * channels * 2 * (sizeof(FbSignalState) + ((size_t)bc * kFbFrame + kFbRing) * sizeof(double));
+  }
+  return b;
+}
+
+extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double level_db, int n_pairs,
+                              const float* d_ref, const float* d_test, size_t pair_stride, const uint32_t* n_ref,
+                              const uint32_t* n_test, uint32_t n_uniform, peaq_result* d_results, void* stream_) {
+  if (!c) return fail(PEAQ_ERR_ARG, "peaq_batch_run: ctx is NULL");
+  if (channels != 1 && channels != 2) return fail(PEAQ_ERR_ARG, "peaq_batch_run: channels must be 1 or 2");
+  if (n_pairs < 0) return fail(PEAQ_ERR_ARG, "peaq_batch_run: n_pairs < 0");
+  if (n_pairs == 0) return PEAQ_OK;
+  if (!d_ref || !d_test || !d_results) return fail(PEAQ_ERR_ARG, "peaq_batch_run: NULL buffer");
+  if ((n_ref == nullptr) != (n_test == nullptr))
+    return fail(PEAQ_ERR_ARG, "peaq_batch_run: give both n_ref and n_test or neither");
+  if (advanced) return fail(PEAQ_ERR_STATE, "peaq_batch_run: advanced mode not wired up yet");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->batch_pending) {            // the workspace is still owned by the previous call
+    HIP_TRY(hipEventSynchronize(c->batch_end));
+    c->batch_pending = false;
+  }
+  c->spans.clear();
+  c->events_used = 0;
+
+  // ---- frame counts -------------------------------------------------------------------
+  uint32_t max_frames = 0;
+  const uint32_t* d_nref = nullptr;
+  const uint32_t* d_ntest = nullptr;
+  const uint32_t* d_nframes = nullptr;
+  if (n_ref) {
+    std::vector<uint32_t> h(3 * (size_t)n_pairs);
+    for (int p = 0; p < n_pairs; ++p) {
+      if (n_ref[p] > pair_stride || n_test[p] > pair_stride)
+        return fail(PEAQ_ERR_ARG, "peaq_batch_run: a pair is longer than pair_stride");
+      h[p] = n_ref[p];
+      h[n_pairs + p] = n_test[p];
+      h[2 * (size_t)n_pairs + p] = count_frames(n_ref[p], n_test[p], kFrame, kHop);
+      max_frames = std::max(max_frames, h[2 * (size_t)n_pairs + p]);
+    }
+    HIP_TRY(c->counts.reserve(h.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(c->counts.p, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));      // h goes out of scope
+    d_nref = c->counts.as<uint32_t>();
+    d_ntest = d_nref + n_pairs;
+    d_nframes = d_nref + 2 * (size_t)n_pairs;
+  } else {
+    if (n_uniform > pair_stride) return fail(PEAQ_ERR_ARG, "peaq_batch_run: n_uniform > pair_stride");
+    max_frames = count_frames(n_uniform, n_uniform, kFrame, kHop);
+  }
+
+  const unsigned fc = frames_per_chunk(n_pairs, channels, max_frames);
+  HIP_TRY(c->records.reserve((size_t)n_pairs * fc * channels * kRecDoubles * sizeof(double)));
+  HIP_TRY(c->state.reserve((size_t)n_pairs * sizeof(PairState)));
+
+  HIP_TRY(hipEventRecord(c->batch_begin, stream));
+  HIP_TRY(launch_state_init(c->state.as<PairState>(), advanced, n_pairs, stream));
+
+  FrontendArgs fa{};
+  fa.ref = d_ref;
+  fa.test = d_test;
+  fa.pair_stride = pair_stride;
+  fa.n_ref = d_nref;
+  fa.n_test = d_ntest;
+  fa.n_uniform_ref = n_uniform;
+  fa.n_uniform_test = n_uniform;
+  fa.n_frames = d_nframes;
+  fa.n_frames_uniform = max_frames;
+  fa.frame_origin = 0;
+  fa.off_ref = 0;
+  fa.off_test = 0;
+  fa.channels = channels;
+  fa.level_factor = fft_level_factor(level_db);
+  fa.common = c->d_common;
+  fa.bands = c->d_bands109;
+  fa.records = c->records.as<double>();
+  BackendArgs ba{};
+  ba.records = fa.records;
+  ba.n_frames = d_nframes;
+  ba.n_frames_uniform = max_frames;
+  ba.channels = channels;
+  ba.advanced = 0;
+  ba.bands = c->d_bands109;
+  ba.state = c->state.as<PairState>();
+
+  for (uint32_t f0 = 0; f0 < max_frames; f0 += fc) {
+    const unsigned nf = std::min<uint32_t>(fc, max_frames - f0);
+    fa.frame0 = f0;
+    fa.frames_per_launch = nf;
+    ba.frame0 = f0;
+    ba.frames_per_launch = nf;
+    hipEvent_t e0 = c->next_event(), e1 = c->next_event(), e2 = c->next_event();
+    if (!e0 || !e1 || !e2) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(e0, stream));
+    HIP_TRY(launch_frontend(109, fa, n_pairs, stream));
+    HIP_TRY(hipEventRecord(e1, stream));
+    HIP_TRY(launch_backend(ba, n_pairs, stream));
+    HIP_TRY(hipEventRecord(e2, stream));
+    c->spans.push_back({e0, e1, 0});
+    c->spans.push_back({e1, e2, 1});
+  }
+  HIP_TRY(launch_finalize(c->state.as<PairState>(), advanced, channels, n_pairs,
+                          reinterpret_cast<ResultRecord*>(d_results), stream));
+  HIP_TRY(hipEventRecord(c->batch_end, stream));
+  c->batch_pending = true;
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_batch_last_timing(peaq_ctx* c, peaq_batch_timing* out) {
+  if (!c || !out) return fail(PEAQ_ERR_ARG, "peaq_batch_last_timing: NULL argument");
+  std::lock_guard<std::mutex> lock(c->mu);
+  std::memset(out, 0, sizeof *out);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventSynchronize(c->batch_end));
+  c->batch_pending = false;
+  HIP_TRY(hipEventElapsedTime(&out->total_ms, c->batch_begin, c->batch_end));
+  for (const TimedSpan& s : c->spans) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
+    if (s.kind == 0) {
+      out->frontend_ms += ms;
+      out->frontend_launches++;
+    } else if (s.kind == 1) {
+      out->backend_ms += ms;
+      out->backend_launches++;
+    } else {
+      out->fb_ms += ms;
+      out->fb_launches++;
+    }
+  }
+  return PEAQ_OK;
+}
+
+// ---------------------------------------------------------------------------
+// synthetic workload
+// ---------------------------------------------------------------------------
+extern "C" int peaq_synth_fill(peaq_ctx* c, uint32_t seed0, int n_pairs, int channels, uint32_t n_samples,
+                               size_t pair_stride, float* d_ref, float* d_test, void* stream) {
+  if (!c || !d_ref || !d_test) return fail(PEAQ_ERR_ARG, "peaq_synth_fill: NULL argument");
+  if (channels != 1 && channels != 2) return fail(PEAQ_ERR_ARG, "peaq_synth_fill: channels must be 1 or 2");
+  if (n_samples > pair_stride) return fail(PEAQ_ERR_ARG, "peaq_synth_fill: n_samples > pair_stride");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(launch_synth(seed0, n_pairs, channels, n_samples, pair_stride, d_ref, d_test,
+                       static_cast<hipStream_t>(stream)));
+  return PEAQ_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stage-level access for parity tests
+// ---------------------------------------------------------------------------
+extern "C" int peaq_debug_frontend(peaq_ctx* c, int bands, int channels, double level_db, const float* d_ref,
+                                   const float* d_test, uint32_t n_ref, uint32_t n_test, int n_frames,
+                                   double* host_out) {
+  if (!c || !d_ref || !d_test || !host_out) return fail(PEAQ_ERR_ARG, "peaq_debug_frontend: NULL argument");
+  if (bands != 109 && bands != 55) return fail(PEAQ_ERR_ARG, "peaq_debug_frontend: bands must be 109 or 55");
+  if (channels != 1 && channels != 2) return fail(PEAQ_ERR_ARG, "peaq_debug_frontend: channels must be 1 or 2");
+  const uint32_t total = count_frames(n_ref, n_test, kFrame, kHop);
+  if (n_frames < 0 || (uint32_t)n_frames > total) return fail(PEAQ_ERR_ARG, "peaq_debug_frontend: too many frames");
+  if (n_frames == 0) return PEAQ_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t bytes = (size_t)n_frames * channels * kRecDoubles * sizeof(double);
+  double* d_rec = nullptr;
+  HIP_TRY(hipMalloc(&d_rec, bytes));
+  HIP_TRY(hipMemset(d_rec, 0, bytes));
+  uint32_t h_n[2] = {n_ref, n_test};
+  uint32_t* d_n = nullptr;
+  HIP_TRY(hipMalloc(&d_n, sizeof h_n));
+  HIP_TRY(hipMemcpy(d_n, h_n, sizeof h_n, hipMemcpyHostToDevice));
+  FrontendArgs fa{};
+  fa.ref = d_ref;
+  fa.test = d_test;
+  fa.pair_stride = std::max(n_ref, n_test);
+  fa.n_ref = d_n;
+  fa.n_test = d_n + 1;
+  fa.n_frames = nullptr;
+  fa.n_frames_uniform = total;
+  fa.channels = channels;
+  fa.frame0 = 0;
+  fa.frames_per_launch = n_frames;
+  fa.level_factor = fft_level_factor(level_db);
+  fa.common = c->d_common;
+  fa.bands = bands == 109 ? c->d_bands109 : c->d_bands55;
+  fa.records = d_rec;
+  hipError_t e = launch_frontend(bands, fa, 1, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(host_out, d_rec, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(d_rec);
+  (void)hipFree(d_n);
+  if (e != hipSuccess) return fail(PEAQ_ERR_DEVICE, std::string("peaq_debug_frontend: ") + hipGetErrorString(e));
+  return PEAQ_OK;
+}
+
+// ---------------------------------------------------------------------------
+// sessions: one per `peaq` element instance
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr unsigned kSessionMaxFrames = 64;   // FFT frames per launch of a session
+
+// host-side stand-in for a GstAdapter: the not yet consumed tail of one pad's stream
+struct PadFifo {
+  std::vector<float> buf;   // interleaved
+  uint64_t base = 0;        // stream sample index (per channel) of buf[0]
+  uint64_t total = 0;       // samples (per channel) pushed so far
+};
+
+}  // namespace
+
+struct peaq_session {
+  peaq_ctx* ctx = nullptr;
+  int advanced = 0, channels = 1;
+  double level_db = 92.;
+  std::mutex mu;
+  PadFifo pad[2];
+  uint64_t fft_pos[2] = {0, 0};   // stream sample where the next FFT frame starts, per pad
+  uint32_t frames_done = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t staged = nullptr;    // the pinned staging buffers may be rewritten after this
+  bool staged_pending = false;
+  float* h_stage[2] = {nullptr, nullptr};   // pinned
+  DevBuf d_sig[2], records, state, result;
+  size_t stage_samples = 0;
+};
+
+static int session_alloc(peaq_session* s) {
+  s->stage_samples = (size_t)(kSessionMaxFrames - 1) * kHop + kFrame;
+  const size_t bytes = s->stage_samples * s->channels * sizeof(float);
+  for (int p = 0; p < 2; ++p) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_stage[p]), bytes, hipHostMallocDefault));
+    HIP_TRY(s->d_sig[p].reserve(bytes));
+  }
+  HIP_TRY(s->records.reserve((size_t)kSessionMaxFrames * s->channels * kRecDoubles * sizeof(double)));
+  HIP_TRY(s->state.reserve(sizeof(PairState)));
+  HIP_TRY(s->result.reserve(sizeof(ResultRecord)));
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&s->staged, hipEventDisableTiming));
+  HIP_TRY(launch_state_init(s->state.as<PairState>(), s->advanced, 1, s->stream));
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_session_create(peaq_ctx* c, int advanced, int channels, double level_db, peaq_session** out) {
+  if (!c || !out) return fail(PEAQ_ERR_ARG, "peaq_session_create: NULL argument");
+  *out = nullptr;
+  if (channels != 1 && channels != 2) return fail(PEAQ_ERR_ARG, "peaq_session_create: channels must be 1 or 2");
+  if (!(level_db >= 0. && level_db <= 130.))
+    return fail(PEAQ_ERR_ARG, "peaq_session_create: playback level outside 0..130 dB (gstpeaq.c:275-281)");
+  if (advanced) return fail(PEAQ_ERR_STATE, "peaq_session_create: advanced mode not wired up yet");
+  HIP_TRY(hipSetDevice(c->device));
+  peaq_session* s = new (std::nothrow) peaq_session;
+  if (!s) return fail(PEAQ_ERR_NOMEM, "out of host memory");
+  s->ctx = c;
+  s->advanced = advanced ? 1 : 0;
+  s->channels = channels;
+  s->level_db = level_db;
+  const int rc = session_alloc(s);
+  if (rc != PEAQ_OK) {
+    peaq_session_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return PEAQ_OK;
+}
+
+extern "C" void peaq_session_destroy(peaq_session* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->ctx->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (int p = 0; p < 2; ++p) {
+    if (s->h_stage[p]) (void)hipHostFree(s->h_stage[p]);
+    s->d_sig[p].release();
+  }
+  s->records.release();
+  s->state.release();
+  s->result.release();
+  if (s->staged) (void)hipEventDestroy(s->staged);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+// run `nf` FFT frames whose first sample is fft_pos[] on each pad; the two
+// signals contribute n_valid[] samples (shorter than a whole frame only for
+// the flush frame).
+static int session_run_frames(peaq_session* s, unsigned nf, const uint64_t n_valid[2]) {
+  peaq_ctx* c = s->ctx;
+  if (s->staged_pending) {
+    HIP_TRY(hipEventSynchronize(s->staged));
+    s->staged_pending = false;
+  }
+  for (int p = 0; p < 2; ++p) {
+    const PadFifo& f = s->pad[p];
+    const size_t off = (size_t)(s->fft_pos[p] - f.base) * s->channels;
+    const size_t cnt = (size_t)n_valid[p] * s->channels;
+    if (cnt) {
+      std::memcpy(s->h_stage[p], f.buf.data() + off, cnt * sizeof(float));
+      HIP_TRY(hipMemcpyAsync(s->d_sig[p].p, s->h_stage[p], cnt * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    }
+  }
+  HIP_TRY(hipEventRecord(s->staged, s->stream));
+  s->staged_pending = true;
+  FrontendArgs fa{};
+  fa.ref = s->d_sig[0].as<float>();
+  fa.test = s->d_sig[1].as<float>();
+  fa.pair_stride = s->stage_samples;
+  fa.n_uniform_ref = static_cast<uint32_t>(n_valid[0]);
+  fa.n_uniform_test = static_cast<uint32_t>(n_valid[1]);
+  fa.n_frames_uniform = s->frames_done + nf;
+  fa.frame_origin = s->frames_done;
+  fa.channels = s->channels;
+  fa.frame0 = s->frames_done;
+  fa.frames_per_launch = nf;
+  fa.level_factor = fft_level_factor(s->level_db);
+  fa.common = c->d_common;
+  fa.bands = c->d_bands109;
+  fa.records = s->records.as<double>();
+  HIP_TRY(launch_frontend(109, fa, 1, s->stream));
+  BackendArgs ba{};
+  ba.records = fa.records;
+  ba.frame0 = s->frames_done;
+  ba.frames_per_launch = nf;
+  ba.n_frames_uniform = s->frames_done + nf;
+  ba.channels = s->channels;
+  ba.advanced = 0;
+  ba.bands = c->d_bands109;
+  ba.state = s->state.as<PairState>();
+  HIP_TRY(launch_backend(ba, 1, s->stream));
+  s->frames_done += nf;
+  return PEAQ_OK;
+}
+
+static void session_trim(peaq_session* s) {
+  for (int p = 0; p < 2; ++p) {
+    PadFifo& f = s->pad[p];
+    const uint64_t keep_from = s->fft_pos[p];
+    if (keep_from > f.base) {
+      const size_t drop = (size_t)(keep_from - f.base) * s->channels;
+      f.buf.erase(f.buf.begin(), f.buf.begin() + std::min(drop, f.buf.size()));
+      f.base = keep_from;
+    }
+  }
+}
+
+// do_processing (gstpeaq.c:596-611)
+static int session_drain(peaq_session* s) {
+  for (;;) {
+    const uint64_t av = std::min(s->pad[0].total - s->fft_pos[0], s->pad[1].total - s->fft_pos[1]);
+    if (av < (uint64_t)kFrame) break;
+    const uint64_t ready = (av - kFrame) / kHop + 1;
+    const unsigned nf = static_cast<unsigned>(std::min<uint64_t>(ready, kSessionMaxFrames));
+    const uint64_t need = (uint64_t)(nf - 1) * kHop + kFrame;
+    const uint64_t nv[2] = {need, need};
+    const int rc = session_run_frames(s, nf, nv);
+    if (rc != PEAQ_OK) return rc;
+    s->fft_pos[0] += (uint64_t)nf * kHop;
+    s->fft_pos[1] += (uint64_t)nf * kHop;
+  }
+  session_trim(s);
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_session_push(peaq_session* s, int pad, const float* data, size_t n) {
+  if (!s) return fail(PEAQ_ERR_ARG, "peaq_session_push: session is NULL");
+  if (pad != 0 && pad != 1) return fail(PEAQ_ERR_ARG, "peaq_session_push: pad must be 0 (ref) or 1 (test)");
+  if (n == 0) return PEAQ_OK;
+  if (!data) return fail(PEAQ_ERR_ARG, "peaq_session_push: data is NULL");
+  std::lock_guard<std::mutex> lock(s->mu);          // GST_OBJECT_LOCK in pad_chain (gstpeaq.c:619)
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  PadFifo& f = s->pad[pad];
+  try {
+    f.buf.insert(f.buf.end(), data, data + n * s->channels);
+  } catch (const std::bad_alloc&) {
+    return fail(PEAQ_ERR_NOMEM, "out of host memory");
+  }
+  f.total += n;
+  return session_drain(s);
+}
+
+// do_flush (gstpeaq.c:716-745)
+extern "C" int peaq_session_flush(peaq_session* s) {
+  if (!s) return fail(PEAQ_ERR_ARG, "peaq_session_flush: session is NULL");
+  std::lock_guard<std::mutex> lock(s->mu);
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  const uint64_t left_r = s->pad[0].total - s->fft_pos[0], left_t = s->pad[1].total - s->fft_pos[1];
+  if (left_r || left_t) {
+    const uint64_t nv[2] = {std::min<uint64_t>(left_r, kFrame), std::min<uint64_t>(left_t, kFrame)};
+    const int rc = session_run_frames(s, 1, nv);
+    if (rc != PEAQ_OK) return rc;
+    s->fft_pos[0] += nv[0];
+    s->fft_pos[1] += nv[1];
+    session_trim(s);
+  }
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_session_results(peaq_session* s, peaq_result* out) {
+  if (!s || !out) return fail(PEAQ_ERR_ARG, "peaq_session_results: NULL argument");
+  std::lock_guard<std::mutex> lock(s->mu);
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  HIP_TRY(launch_finalize(s->state.as<PairState>(), s->advanced, s->channels, 1, s->result.as<ResultRecord>(),
+                          s->stream));
+  HIP_TRY(hipMemcpyAsync(out, s->result.p, sizeof(peaq_result), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_session_reset(peaq_session* s) {
+  if (!s) return fail(PEAQ_ERR_ARG, "peaq_session_reset: session is NULL");
+  std::lock_guard<std::mutex> lock(s->mu);
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  for (int p = 0; p < 2; ++p) {
+    s->pad[p] = PadFifo();
+    s->fft_pos[p] = 0;
+  }
+  s->frames_done = 0;
+  HIP_TRY(launch_state_init(s->state.as<PairState>(), s->advanced, 1, s->stream));
+  return PEAQ_OK;
+}

@@ -1,0 +1,132 @@
+// peaq_device.h -- data layouts shared by the host code and the HIP kernels.
+//
+// Everything here lives in HBM.  Terminology follows the reference's domain:
+// pair = one (reference, test) signal pair; frame = one 2048-sample FFT frame
+// (hop 1024) of a pair; block = one 192-sample filter-bank block (advanced);
+// band = critical band (109 basic / 55 advanced FFT model / 40 filter bank);
+// MOV = model output variable.
+#pragma once
+
+#include <stdint.h>
+
+namespace peaq {
+
+constexpr int kFrame      = 2048;   // fftearmodel.c:51
+constexpr int kHop        = 1024;   // fftearmodel.c:226
+constexpr int kBins       = 1025;
+constexpr int kBandStride = 112;    // band vectors are padded to 112 doubles
+constexpr int kFbFrame    = 192;    // fbearmodel.c:48
+constexpr int kFbBands    = 40;
+constexpr int kFbRing     = 1456;   // fbearmodel.c:52
+constexpr int kFbTaps     = 11;     // backward-masking FIR history (fbearmodel.c:262)
+
+// ---- constant tables (built on the host in FP64, peaq_tables.cpp) ----------
+struct CommonTables {
+  double hann[kFrame];          // fftearmodel.c:167-172
+  double ear_w2[kBins];         // fftearmodel.c:253-256
+  double tw_re[kFrame];         // exp(-2 pi i k / 2048), k = 0..2047
+  double tw_im[kFrame];
+  double ehs_window[256];       // movs.c:1366-1367
+};
+
+struct BandTables {             // earmodel.c:279-323 + fftearmodel.c:693-788
+  int    bands;
+  int    step;                  // hop in samples
+  double delta_z;
+  double dz02;                  // 0.2 * delta_z
+  double aLe;                   // (1/a_L)^0.4
+  double deriv_factor;          // 48000 / step (modpatt.c:231)
+  double fc[kBandStride];
+  double internal_noise[kBandStride];
+  double noise_pow03[kBandStride];      // internal_noise^0.3 (movs.c:243)
+  double ear_tc[kBandStride];
+  double adapt_tc[kBandStride];
+  double exc_threshold[kBandStride];
+  double threshold[kBandStride];
+  double loud_factor[kBandStride];
+  // FFT model only
+  int    lo[kBandStride], hi[kBandStride];
+  double wlo[kBandStride], whi[kBandStride];
+  double ln_aUC[kBandStride];
+  double gIL[kBandStride];
+  double inv_spread_norm[kBandStride];
+  double mask_diff[kBandStride];
+};
+
+struct FbTables {               // fbearmodel.c:57-61,182-225
+  int    flen[kFbBands];
+  int    delay[kFbBands];       // D = 1 + (1456 - N)/2
+  int    coef_off[kFbBands];    // offset of band's coefficients in h_re/h_im
+  double back_mask[6];
+  double h_re[12000];           // sum(N/2+1) = 10954 coefficients
+  double h_im[12000];
+};
+
+// ---- per-frame record: front end -> back end --------------------------------
+// One record per (pair, frame, channel), kRecDoubles doubles.
+constexpr int kRecUnsmRef   = 0 * kBandStride;   // unsmeared excitation, reference
+constexpr int kRecUnsmTest  = 1 * kBandStride;
+constexpr int kRecLoudRef   = 2 * kBandStride;   // unsmeared^0.3 (modpatt.c:235)
+constexpr int kRecLoudTest  = 3 * kBandStride;
+constexpr int kRecNoise     = 4 * kBandStride;   // noise in bands (movs.c:992-1000)
+constexpr int kRecScalars   = 5 * kBandStride;   // 560
+constexpr int kRecBwRef     = kRecScalars + 0;
+constexpr int kRecBwTest    = kRecScalars + 1;
+constexpr int kRecEhs       = kRecScalars + 2;   // EHS of this frame (not yet x1000)
+constexpr int kRecFlagsRef  = kRecScalars + 3;   // bit0 above-threshold (ref), bit1 energy(ref)
+constexpr int kRecFlagsTest = kRecScalars + 4;   // bit1 energy(test)
+constexpr int kRecSigE      = kRecScalars + 5;   // sum ref^2 over the hop (totalsnr)
+constexpr int kRecNoiseE    = kRecScalars + 6;   // sum (ref-test)^2
+constexpr int kRecDoubles   = 576;               // == PEAQ_DEBUG_RECORD_DOUBLES
+
+// filter-bank record per (pair, block, channel): unsmeared/excitation of both
+// signals + above-threshold flag
+constexpr int kFbRecUnsmRef  = 0;
+constexpr int kFbRecUnsmTest = 40;
+constexpr int kFbRecExcRef   = 80;
+constexpr int kFbRecExcTest  = 120;
+constexpr int kFbRecFlags    = 160;
+constexpr int kFbRecDoubles  = 168;
+
+// ---- recurrent state of one pair --------------------------------------------
+constexpr int kAccFields = 12;  // num, den, num2, past0..2, max, filt, saved num, den, num2, max
+constexpr int kMaxAcc    = 11;
+
+enum AccMode { kAvg = 0, kAvgLog, kRms, kRmsAsym, kAvgWindow, kFilteredMax, kAdb };
+enum AccStatus { kInit = 0, kNormal, kTentative };
+
+enum StateVec {                 // band vectors per channel
+  kSmearRef = 0, kSmearTest,    // fftearmodel.c:498-500 filtered excitation (FFT model)
+  kLaFiltRef, kLaFiltTest, kLaNum, kLaDen, kLaPcRef, kLaPcTest,     // leveladapter.c:57-70
+  kModPrevRef, kModLoudRef, kModDLoudRef,                           // modpatt.c:57-66
+  kModPrevTest, kModLoudTest, kModDLoudTest,
+  kStateVecs
+};
+
+struct ChannelState {
+  double vec[kStateVecs][kBandStride];
+  double acc[kMaxAcc][kAccFields];
+};
+
+struct PairState {
+  uint32_t frame_counter;       // gstpeaq.c:124
+  uint32_t fb_counter;          // gstpeaq.c:125
+  uint32_t loudness_reached;    // gstpeaq.c:126, starts at UINT_MAX
+  uint32_t pad0;
+  int32_t  status[kMaxAcc];     // movaccum.c:95-108
+  int32_t  pad1;
+  double   sig_energy;          // gstpeaq.c:137-138
+  double   noise_energy;
+  ChannelState ch[2];
+};
+
+// filter-bank ear-model state of one (pair, channel, signal)  (fbearmodel.c:93-107)
+struct FbSignalState {
+  double hp[6];                 // hpfilter1_x1,x2,y1,y2, hpfilter2_y1,y2
+  double cu[kFbBands];
+  double e0_hist[kFbBands][kFbTaps];
+  double excitation[kFbBands];
+  double ring[kFbRing];         // the last 1456 filtered samples, newest first
+};
+
+}  // namespace peaq

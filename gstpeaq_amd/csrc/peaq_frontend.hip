@@ -1,0 +1,523 @@
+// peaq_frontend.hip -- the stateless half of the FFT ear model, one workgroup
+// of two wavefronts per (pair, frame, channel): wave 0 transforms the reference
+// frame, wave 1 the test frame, with IDENTICAL instruction streams (identical
+// inputs must give bit-identical spectra, otherwise the reference's
+// "identical signals" behaviour -- exact zeros in the noise spectrum and in the
+// EHS log-ratio, SURVEY.md Appendix B.10 -- is lost).
+//
+// Per wave (reference fftearmodel.c:433-515 up to `unsmeared_excitation`):
+//   Hann window * samples            :451-452
+//   2048-point real DFT              :457   (as a 1024-point complex Stockham
+//                                            FFT 16x16x4 in registers + LDS and
+//                                            the even/odd split)
+//   power spectrum * level factor    :464-466
+//   outer/middle ear weighting       :470-472
+//   grouping into critical bands     :604-620
+//   + internal noise                 :483-485
+//   level-dependent spreading        :637-676
+//   energy flag                      :508-514
+// plus the frame's stateless MOV ingredients, after one workgroup barrier:
+//   ref wave : error harmonic structure    movs.c:1346-1443
+//   test wave: noise-in-bands for NMR      movs.c:992-1000
+//              bandwidths                  movs.c:776-809
+//              totalsnr energies           gstpeaq.c:913-918
+//   ref wave : data-boundary detector      gstpeaq.c:1081-1099 (before the FFT)
+//
+// LDS per wave ("unit"), 18496 B: the 17 KiB FFT exchange buffer is reused for
+// the power spectrum P[0..1023], the weighted spectrum Pw[0..775] and 4 KiB of
+// scratch.  All LDS traffic before the barrier is wave-private.
+#include <hip/hip_runtime.h>
+
+#include "peaq_device.h"
+#include "peaq_kernels.h"
+#include "peaq_wave.h"
+
+namespace peaq {
+
+constexpr int kUnitDoubles = 2312;            // 18496 B per wave
+constexpr int kOffP = 0;                      // P[1024]
+constexpr int kOffPw = 1024;                  // Pw[776]
+constexpr int kOffScratch = 1800;             // 512 doubles
+constexpr int kPwLen = 776;
+
+__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }   // complex index -> padded slot
+
+__device__ __forceinline__ cplx lds_ldc(const double* base, int idx) {
+  const double2 v = *reinterpret_cast<const double2*>(base + 2 * pad16(idx));
+  return {v.x, v.y};
+}
+__device__ __forceinline__ void lds_stc(double* base, int idx, cplx v) {
+  *reinterpret_cast<double2*>(base + 2 * pad16(idx)) = make_double2(v.re, v.im);
+}
+
+// ---------------------------------------------------------------------------
+// 2048-point real DFT of one frame held as z[r] = x[2n] + i x[2n+1], n = lane + 64 r.
+// On return P/Pw of the unit hold the (weighted) power spectrum.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double* unit, int lane,
+                                                     const CommonTables* __restrict__ ct,
+                                                     double level_factor) {
+  // pass 1: radix 16, sub-transform size 1 -> out[16 lane + r]
+  dft16(z);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lds_stc(unit, 16 * lane + r, z[r]);
+  wave_lds_fence();
+  // pass 2: radix 16, sub-transform size 16
+  {
+    const int k = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = lds_ldc(unit, lane + 64 * r);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {
+      const int t = 8 * r * k;                         // W_256^(r k) = W_2048^(8 r k)
+      z[r] = cmul(z[r], {ct->tw_re[t], ct->tw_im[t]});
+    }
+    dft16(z);
+    const int j = (lane - k) * 16 + k;
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds_stc(unit, j + 16 * r, z[r]);
+  }
+  wave_lds_fence();
+  // pass 3: radix 4, sub-transform size 256; four butterflies per lane
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[m + 4 * r] = lds_ldc(unit, lane + 64 * m + 256 * r);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int i = lane + 64 * m;
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      const int t = 2 * r * i;                         // W_1024^(r i) = W_2048^(2 r i)
+      z[m + 4 * r] = cmul(z[m + 4 * r], {ct->tw_re[t], ct->tw_im[t]});
+    }
+    dft4(z[m], z[m + 4], z[m + 8], z[m + 12]);
+  }
+  // z[q] = Z[lane + 64 q].  Publish, then fetch the mirror bins Z[1024 - k].
+  wave_lds_fence();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) lds_stc(unit, lane + 64 * q, z[q]);
+  wave_lds_fence();
+  cplx zm[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) zm[q] = lds_ldc(unit, (1024 - (lane + 64 * q)) & 1023);
+  wave_lds_fence();
+  // even/odd split: X[k] = E[k] + W_2048^k O[k]
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int k = lane + 64 * q;
+    const cplx e = {0.5 * (z[q].re + zm[q].re), 0.5 * (z[q].im - zm[q].im)};
+    const cplx o = {0.5 * (z[q].im + zm[q].im), -0.5 * (z[q].re - zm[q].re)};
+    const cplx x = cadd(e, cmul({ct->tw_re[k], ct->tw_im[k]}, o));
+    const double p = (x.re * x.re + x.im * x.im) * level_factor;     // fftearmodel.c:464-466
+    unit[kOffP + k] = p;
+    if (k < kPwLen) unit[kOffPw + k] = p * ct->ear_w2[k];             // fftearmodel.c:470-472
+  }
+  wave_lds_fence();
+}
+
+// critical-band grouping of a spectrum held in LDS (fftearmodel.c:604-620)
+template <typename F>
+__device__ __forceinline__ double group_band(const BandTables* __restrict__ bt, int b, F spec) {
+  const int lo = bt->lo[b], hi = bt->hi[b];
+  double p = bt->wlo[b] * spec(lo) + bt->whi[b] * spec(hi);
+  for (int k = lo + 1; k < hi; ++k) p += spec(k);
+  return p < 1e-12 ? 1e-12 : p;
+}
+
+// ---------------------------------------------------------------------------
+// Data-boundary detector (gstpeaq.c:1081-1099), bit-exact: the reference keeps
+// a FLOAT running sum of |x| over 5 samples and tests it from i = 5 on.  The
+// exact 5-sample window sums decide unless they come within the float sum's
+// worst-case drift (< 5e-7 over 2048 steps) of the threshold; only then one
+// lane replays the sequential float recurrence.  `ax` = |x| staged in LDS.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int boundary_detect(const float* ax, int n, int lane) {
+  const double thr = 200. / 32768;
+  double wmax = 0.;
+  for (int i = 5 + lane; i < n; i += 64) {
+    const double w = (double)ax[i] + (double)ax[i - 1] + (double)ax[i - 2] + (double)ax[i - 3] + (double)ax[i - 4];
+    wmax = fmax(wmax, w);
+  }
+  wmax = wave_max(wmax);
+  if (wmax >= thr + 1e-6) return 1;
+  if (wmax < thr - 1e-6) return 0;
+  int res = 0;
+  if (lane == 0) {
+    float sum = 0;
+    for (int i = 0; i < 5; ++i) sum = (float)((double)sum + (double)ax[i]);
+    for (int i = 5; i < n; ++i) {
+      sum = (float)((double)sum + ((double)ax[i] - (double)ax[i - 5]));
+      if ((double)sum >= thr) {
+        res = 1;
+        break;
+      }
+    }
+  }
+  return __shfl(res, 0, 64);
+}
+
+// XCD-aware bijective remap (the dispatcher places block b on XCD b % 8): work
+// items that share input cache lines -- the two channels of a frame and the
+// 50 %-overlapping neighbour frames -- become neighbours on ONE XCD's L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
+  const unsigned q = n >> 3, r = n & 7, xcd = b & 7, slot = b >> 3;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+struct FrameSrc {
+  const float* x;
+  long long s0, n_valid;
+  int channels, chan;
+  bool whole;
+  // samples 2n and 2n+1 of the frame
+  __device__ __forceinline__ void load2(int n, float& x0, float& x1) const {
+    if (whole) {
+      if (channels == 1) {
+        const float2 v = *reinterpret_cast<const float2*>(x + s0 + 2 * n);
+        x0 = v.x;
+        x1 = v.y;
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(x + (s0 + 2 * n) * 2);
+        x0 = chan ? v.y : v.x;
+        x1 = chan ? v.w : v.z;
+      }
+    } else {                                         // zero-padded flush frame (gstpeaq.c:733-738)
+      const long long i0 = s0 + 2 * n, i1 = i0 + 1;
+      x0 = i0 < n_valid ? x[i0 * channels + chan] : 0.f;
+      x1 = i1 < n_valid ? x[i1 * channels + chan] : 0.f;
+    }
+  }
+};
+
+template <int NB>
+__global__ __launch_bounds__(128) void frontend_kernel(FrontendArgs a) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63;
+  const int sig = threadIdx.x >> 6;                  // 0 = reference wave, 1 = test wave
+  double* unit = lds + sig * kUnitDoubles;
+  double* scratch = unit + kOffScratch;
+  const CommonTables* __restrict__ ct = a.common;
+  const BandTables* __restrict__ bt = a.bands;
+
+  // ---- which (pair, frame, channel) -------------------------------------------
+  const unsigned item = xcd_remap(blockIdx.x, gridDim.x);
+  const int chan = item % a.channels;
+  const unsigned fl = (item / a.channels) % a.frames_per_launch;
+  const unsigned pair = item / (a.channels * a.frames_per_launch);
+  const unsigned frame = a.frame0 + fl;
+  const unsigned n_ref = a.n_ref ? a.n_ref[pair] : a.n_uniform_ref;
+  const unsigned n_test = a.n_test ? a.n_test[pair] : a.n_uniform_test;
+  const unsigned n_frames = a.n_frames ? a.n_frames[pair] : a.n_frames_uniform;
+  if (frame >= n_frames) return;                     // whole workgroup leaves together
+  const size_t pair_off = (size_t)pair * a.pair_stride * a.channels;
+  FrameSrc src_ref, src_test;
+  src_ref.x = a.ref + pair_off;
+  src_test.x = a.test + pair_off;
+  src_ref.s0 = (long long)(frame - a.frame_origin) * kHop + a.off_ref;
+  src_test.s0 = (long long)(frame - a.frame_origin) * kHop + a.off_test;
+  src_ref.n_valid = (long long)n_ref;
+  src_test.n_valid = (long long)n_test;
+  src_ref.channels = src_test.channels = a.channels;
+  src_ref.chan = src_test.chan = chan;
+  // vector loads need the whole frame in range and a 8 B (mono) / 16 B (stereo) aligned start
+  const size_t amask = a.channels == 1 ? 7 : 15;
+  src_ref.whole = src_ref.s0 + kFrame <= src_ref.n_valid &&
+                  ((reinterpret_cast<size_t>(src_ref.x + src_ref.s0 * a.channels) & amask) == 0);
+  src_test.whole = src_test.s0 + kFrame <= src_test.n_valid &&
+                   ((reinterpret_cast<size_t>(src_test.x + src_test.s0 * a.channels) & amask) == 0);
+  const FrameSrc& src = sig ? src_test : src_ref;
+  double* __restrict__ rec =
+      a.records + ((size_t)(pair * a.frames_per_launch + fl) * a.channels + chan) * kRecDoubles;
+
+  // ---- load + window (fftearmodel.c:451-452), energy flag (:508-514) ----------
+  cplx z[16];
+  float amax = 0.f;
+  double energy = 0.;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = lane + 64 * r;
+    float x0, x1;
+    src.load2(n, x0, x1);
+    z[r] = {ct->hann[2 * n] * (double)x0, ct->hann[2 * n + 1] * (double)x1};
+    if (r >= 8) {                                    // samples 1024..2047; float products, double sum
+      energy += (double)(x0 * x0);
+      energy += (double)(x1 * x1);
+    }
+    // a single sample above the threshold settles the boundary detector; sample 0
+    // is excluded because the first tested window is [1..5]
+    amax = fmaxf(amax, n == 0 ? fabsf(x1) : fmaxf(fabsf(x0), fabsf(x1)));
+  }
+  energy = wave_sum(energy);
+  const int energy_flag = energy >= 8000. / (32768. * 32768.);
+
+  int above = 0;
+  if (sig == 0) {
+    const float amax_w = (float)wave_max((double)amax);
+    if ((double)amax_w >= 200. / 32768 + 1e-6) {
+      above = 1;
+    } else {
+      // quiet frame: stage |x| (8 KiB, start of the still unused FFT buffer) and decide exactly
+      float* ax = reinterpret_cast<float*>(unit);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = lane + 64 * r;
+        float x0, x1;
+        src.load2(n, x0, x1);
+        reinterpret_cast<float2*>(ax)[n] = make_float2(fabsf(x0), fabsf(x1));
+      }
+      wave_lds_fence();
+      above = boundary_detect(ax, kFrame, lane);
+      wave_lds_fence();
+    }
+  }
+
+  frame_power_spectrum(z, unit, lane, ct, a.level_factor);
+
+  // ---- critical bands, internal noise, spreading ------------------------------------
+  // lane owns bands 2*lane and 2*lane+1
+  const double* pw = unit + kOffPw;
+  double* e2up = scratch;                            // [224] upward-spreading accumulators
+  for (int i = lane; i < 224; i += 64) e2up[i] = 0.;
+  double ene[2], ae[2];
+  const int b0 = 2 * lane;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int b = b0 + s;
+    if (b < NB) {
+      const double pp = group_band(bt, b, [&](int k) { return pw[k]; }) + bt->internal_noise[b];   // :483-485
+      // Kabal (23)-(24); fftearmodel.c:649-656.  a^y evaluated as exp(y ln a).
+      const double ln_a = bt->ln_aUC[b] + bt->dz02 * log(pp);
+      const double a_uce = exp(ln_a);
+      const double g_iu = (1. - exp((double)(NB - b) * ln_a)) / (1. - a_uce);
+      const double en = pp / (bt->gIL[b] + g_iu - 1.);
+      ae[s] = exp(0.4 * ln_a);
+      ene[s] = pow(en, 0.4);
+    } else {
+      ae[s] = 0.;
+      ene[s] = 0.;
+    }
+  }
+  wave_lds_fence();
+  // upward spreading, Kabal (27): E2[j] += Ene[i] * aUCEe[i]^(j-i) for j > i.
+  // One LDS atomic add per (source band, step); the targets of one instruction
+  // are distinct, so there is no contention.
+  {
+    double r0 = ene[0], r1 = ene[1];
+#pragma unroll 12
+    for (int s = 1; s < NB; ++s) {
+      r0 *= ae[0];
+      r1 *= ae[1];
+      atomicAdd(&e2up[b0 + s], r0);
+      atomicAdd(&e2up[b0 + 1 + s], r1);
+    }
+  }
+  // downward spreading, Kabal (28): E2[i-1] = aLe E2[i] + Ene[i-1]  (suffix scan)
+  double dn0, dn1;
+  {
+    const double al = bt->aLe;
+    double v = ene[0] + al * ene[1];                 // pair-local
+    double m = al * al;                              // ratio per lane step
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double o = __shfl_down(v, d, 64);
+      if (lane + d < 64) v += m * o;
+      m *= m;
+    }
+    const double nxt = __shfl_down(v, 1, 64);        // E2down[2 lane + 2]
+    dn0 = v;
+    dn1 = ene[1] + (lane < 63 ? al * nxt : 0.);
+  }
+  wave_lds_fence();
+  double unsm[2], loud[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int b = b0 + s;
+    const double e2 = (s ? dn1 : dn0) + e2up[b < NB ? b : 0];
+    // (25): E2^(1/0.4) / normalisation; x^2.5 = x^2 sqrt(x)
+    const double e = e2 * e2 * sqrt(e2) * bt->inv_spread_norm[b < NB ? b : 0];
+    unsm[s] = b < NB ? e : 0.;
+    loud[s] = b < NB ? pow(e, 0.3) : 0.;             // modpatt.c:235
+  }
+  if (b0 < kBandStride) {
+    *reinterpret_cast<double2*>(rec + (sig ? kRecUnsmTest : kRecUnsmRef) + b0) = make_double2(unsm[0], unsm[1]);
+    *reinterpret_cast<double2*>(rec + (sig ? kRecLoudTest : kRecLoudRef) + b0) = make_double2(loud[0], loud[1]);
+  }
+  if (lane == 0) {
+    if (sig == 0)
+      rec[kRecFlagsRef] = (double)(above | (energy_flag << 1));
+    else
+      rec[kRecFlagsTest] = (double)(energy_flag << 1);
+  }
+
+  __syncthreads();                                   // both spectra are in LDS
+  const double* p_ref = lds + kOffP;
+  const double* p_test = lds + kUnitDoubles + kOffP;
+  const double* pw_ref = lds + kOffPw;
+  const double* pw_test = lds + kUnitDoubles + kOffPw;
+
+  if (sig == 1) {
+    // ---- noise in bands for the NMR MOVs (movs.c:992-1000) -----------------------
+    double nib[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int b = b0 + s;
+      nib[s] = b < NB ? group_band(bt, b, [&](int k) {
+        const double r = pw_ref[k], t = pw_test[k];
+        return r - 2 * sqrt(r * t) + t;
+      }) : 0.;
+    }
+    if (b0 < kBandStride) *reinterpret_cast<double2*>(rec + kRecNoise + b0) = make_double2(nib[0], nib[1]);
+
+    // ---- bandwidths (movs.c:776-809), unweighted spectrum ------------------------
+    double thr = 0.;                                 // powers are >= 0
+    for (int k = 921 + lane; k < 1024; k += 64) thr = fmax(thr, p_test[k]);
+    thr = wave_max(thr);
+    int bw_ref = 0;
+    for (int k = lane; k < 921; k += 64)
+      if (p_ref[k] > 10. * thr) bw_ref = k + 1;     // ascending k: the last hit is the largest
+    bw_ref = wave_max_i(bw_ref);
+    int bw_test = 0;
+    if (bw_ref > 346) {
+      for (int k = lane; k < bw_ref; k += 64)
+        if (p_test[k] >= 3.16227766016838 * thr) bw_test = k + 1;
+      bw_test = wave_max_i(bw_test);
+    }
+    // ---- totalsnr energies over the hop (gstpeaq.c:913-918; float products) --------
+    double se = 0., ne = 0.;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int n = lane + 64 * r;
+      float r0, r1, t0, t1;
+      src_ref.load2(n, r0, r1);
+      src_test.load2(n, t0, t1);
+      se += (double)(r0 * r0);
+      se += (double)(r1 * r1);
+      ne += (double)((r0 - t0) * (r0 - t0));
+      ne += (double)((r1 - t1) * (r1 - t1));
+    }
+    se = wave_sum(se);
+    ne = wave_sum(ne);
+    if (lane == 0) {
+      rec[kRecBwRef] = (double)bw_ref;
+      rec[kRecBwTest] = (double)bw_test;
+      rec[kRecSigE] = se;
+      rec[kRecNoiseE] = ne;
+    }
+  } else {
+    // ---- error harmonic structure (movs.c:1346-1443), per frame and channel ---------
+    // d[k] = ln(Pw_test/Pw_ref), k < 512
+    double* d = scratch;                             // [512]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = lane + 64 * j;
+      const double fr = pw_ref[k], ft = pw_test[k];
+      d[k] = (fr == 0. && ft == 0.) ? 0. : log(ft / fr);
+    }
+    wave_lds_fence();
+    // c[l] = sum_{k<256} d[k] d[k+l]; lane owns lags lane + 64 m.  (The reference
+    // evaluates the same sums through 512-point FFTs, movs.c:1279-1315.)
+    double c[4] = {0., 0., 0., 0.};
+    for (int k = 0; k < 256; ++k) {
+      const double dk = d[k];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) c[m] = fma(dk, d[k + lane + 64 * m], c[m]);
+    }
+    const double d0 = __shfl(c[0], 0, 64);
+    // running window energy dk[l] = d0 + sum_{j<l} (d[j+256]^2 - d[j]^2)   (:1413-1418)
+    {
+      double g[4], pre = 0.;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = 4 * lane + t;
+        const double hi = d[j + 256], lo = d[j];
+        g[t] = hi * hi - lo * lo;
+      }
+      const double tot = g[0] + g[1] + g[2] + g[3];
+      double inc = tot;                              // inclusive scan over lanes
+#pragma unroll
+      for (int dd = 1; dd < 64; dd <<= 1) {
+        const double o = __shfl_up(inc, dd, 64);
+        if (lane >= dd) inc += o;
+      }
+      pre = d0 + (inc - tot);
+      wave_lds_fence();
+      double run = pre;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        d[4 * lane + t] = run;                       // overwrites d[0..255] (all reads are done)
+        run += g[t];
+      }
+      wave_lds_fence();
+    }
+    double cavg = 0.;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      c[m] /= sqrt(d0 * d[lane + 64 * m]);
+      cavg += c[m];
+    }
+    cavg = wave_sum(cavg) / 256.;
+    // mean removed before windowing (EHS_SUBTRACT_DC_BEFORE_WINDOW 1), 256-point DFT
+    cplx u[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) u[m] = {(c[m] - cavg) * ct->ehs_window[lane + 64 * m], 0.};
+    wave_lds_fence();
+    double2* xb = reinterpret_cast<double2*>(scratch);   // 256 complex
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int p = 1 << (2 * pass);
+      const int k = lane & (p - 1);
+      if (pass > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double2 v = xb[lane + 64 * r];
+          u[r] = {v.x, v.y};
+        }
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+          const int t = r * k * (512 >> (2 * pass));   // W_{4p}^(r k) = W_2048^(r k 512/p)
+          u[r] = cmul(u[r], {ct->tw_re[t], ct->tw_im[t]});
+        }
+      }
+      dft4(u[0], u[1], u[2], u[3]);
+      if (pass < 3) {
+        const int j = (lane - k) * 4 + k;
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xb[j + r * p] = make_double2(u[r].re, u[r].im);
+        wave_lds_fence();
+      }
+    }
+    // u[r] = C[lane + 64 r]; EHS = highest |C|^2 that exceeds its left neighbour, bins 1..128
+    const double s0 = u[0].re * u[0].re + u[0].im * u[0].im;
+    const double s1 = u[1].re * u[1].re + u[1].im * u[1].im;
+    const double s2 = u[2].re * u[2].re + u[2].im * u[2].im;
+    const double s0_up = __shfl_up(s0, 1, 64), s1_up = __shfl_up(s1, 1, 64);
+    const double s0_last = __shfl(s0, 63, 64), s1_last = __shfl(s1, 63, 64);
+    const double prev0 = s0_up;                           // valid for lane >= 1
+    const double prev1 = lane == 0 ? s0_last : s1_up;
+    double best = 0.;
+    if (lane >= 1 && s0 > prev0) best = s0;
+    if (s1 > prev1 && s1 > best) best = s1;
+    if (lane == 0 && s2 > s1_last && s2 > best) best = s2;
+    best = wave_max(best);
+    if (lane == 0) rec[kRecEhs] = best;
+  }
+}
+
+hipError_t launch_frontend(int bands, const FrontendArgs& a, unsigned n_pairs, hipStream_t stream) {
+  const unsigned grid = n_pairs * a.frames_per_launch * a.channels;
+  if (grid == 0) return hipSuccess;
+  const size_t lds = 2 * kUnitDoubles * sizeof(double);
+  if (bands == 109)
+    hipLaunchKernelGGL(frontend_kernel<109>, dim3(grid), dim3(128), lds, stream, a);
+  else if (bands == 55)
+    hipLaunchKernelGGL(frontend_kernel<55>, dim3(grid), dim3(128), lds, stream, a);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace peaq

@@ -1,0 +1,94 @@
+// peaq_kernels.h -- launch interfaces of the HIP kernels (host side sees plain
+// functions; the kernels themselves live in the .hip files).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "peaq_device.h"
+
+namespace peaq {
+
+// ---- FFT ear-model front end -------------------------------------------------
+struct FrontendArgs {
+  const float* ref;             // [pair][pair_stride][channels] interleaved F32
+  const float* test;
+  size_t pair_stride;           // samples (per channel) between consecutive pairs
+  const uint32_t* n_ref;        // per-pair lengths in samples per channel (device), or nullptr
+  const uint32_t* n_test;
+  uint32_t n_uniform_ref;       // lengths used when n_ref/n_test are null
+  uint32_t n_uniform_test;
+  const uint32_t* n_frames;     // per-pair total frame count (device), or nullptr
+  uint32_t n_frames_uniform;
+  // frame f starts at buffer sample (f - frame_origin) * 1024 + off_{ref,test}
+  // (batch: all zero; sessions: the staging buffer holds a window of the stream)
+  unsigned frame_origin;
+  long long off_ref, off_test;
+  int channels;
+  unsigned frame0;              // first frame of this launch
+  unsigned frames_per_launch;
+  double level_factor;          // fftearmodel.c:312-313
+  const CommonTables* common;
+  const BandTables* bands;      // FFT model, 109 or 55 bands
+  double* records;              // [pair][frame - frame0][channel][kRecDoubles]
+};
+hipError_t launch_frontend(int bands, const FrontendArgs& a, unsigned n_pairs, hipStream_t stream);
+
+// ---- pattern back end (time smearing .. MOV accumulation) -------------------
+struct BackendArgs {
+  const double* records;        // as written by the front end
+  unsigned frame0, frames_per_launch;
+  const uint32_t* n_frames;
+  uint32_t n_frames_uniform;
+  int channels;
+  int advanced;                 // 0: basic (109 bands, 11 MOVs); 1: FFT part of advanced (55 bands)
+  const BandTables* bands;
+  PairState* state;             // [pair]
+};
+hipError_t launch_backend(const BackendArgs& a, unsigned n_pairs, hipStream_t stream);
+
+// ---- read-out: accumulators -> MOVs -> DI -> ODG --------------------------------
+struct ResultRecord {           // mirrors peaq_result in include/peaq_amd.h
+  double movs[11];
+  double di, odg, totalsnr, frames, fb_blocks;
+};
+hipError_t launch_finalize(const PairState* state, int advanced, int channels, unsigned n_pairs,
+                           ResultRecord* out, hipStream_t stream);
+hipError_t launch_state_init(PairState* state, int advanced, unsigned n_pairs, hipStream_t stream);
+
+// ---- advanced mode: filter-bank ear model ------------------------------------------
+struct FbFrontArgs {
+  const float* ref;
+  const float* test;
+  size_t pair_stride;
+  const uint32_t* n_ref;
+  const uint32_t* n_test;
+  uint32_t n_uniform;
+  const uint32_t* n_blocks;
+  uint32_t n_blocks_uniform;
+  long long sample_base;
+  int channels;
+  unsigned block0, blocks_per_launch;
+  double level_factor;          // fbearmodel.c:252-253
+  const BandTables* bands;      // 40 bands
+  const FbTables* fb;
+  FbSignalState* fbstate;       // [pair][channel][2]
+  double* hp_scratch;           // [pair][channel][2][blocks_per_launch*192 + 1456]
+  double* records;              // [pair][block - block0][channel][kFbRecDoubles]
+};
+hipError_t launch_fb_frontend(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream);
+
+struct FbBackendArgs {
+  const double* records;
+  unsigned block0, blocks_per_launch;
+  const uint32_t* n_blocks;
+  uint32_t n_blocks_uniform;
+  int channels;
+  const BandTables* bands;
+  PairState* state;
+};
+hipError_t launch_fb_backend(const FbBackendArgs& a, unsigned n_pairs, hipStream_t stream);
+
+// ---- synthetic workload --------------------------------------------------------------
+hipError_t launch_synth(uint32_t seed0, unsigned n_pairs, int channels, uint32_t n_samples, size_t pair_stride,
+                        float* ref, float* test, hipStream_t stream);
+
+}  // namespace peaq

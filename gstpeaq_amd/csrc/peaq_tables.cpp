@@ -1,0 +1,204 @@
+// peaq_tables.cpp -- constant tables of the PEAQ ear models, built once per
+// context on the host in FP64 and uploaded to HBM.
+//
+// What the reference computes at object-construction time:
+//   Hann window            fftearmodel.c:160-173
+//   outer/middle ear       earmodel.c:702-709, fftearmodel.c:249-256
+//   band edges + weights   fftearmodel.c:701-760
+//   spreading constants    fftearmodel.c:723-725,764-767,778-781
+//   masking offsets        fftearmodel.c:770-772
+//   per-band constants     earmodel.c:279-323, 627-635
+//   filter-bank responses  fbearmodel.c:57-61,182-225
+//   EHS window             movs.c:1360-1368
+#include "peaq_tables.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace peaq {
+
+static const double kPi = 3.14159265358979323846;
+static const double kFs = 48000.0;
+
+static double ear_weight_db_to_lin(double f_hz) {
+  // W(f) of BS.1387 (7) / Kabal (6); earmodel.c:702-709
+  const double f = f_hz / 1000.0;
+  const double w_db = -0.6 * 3.64 * std::pow(f, -0.8) + 6.5 * std::exp(-0.6 * std::pow(f - 3.3, 2.0)) -
+                      1e-3 * std::pow(f, 3.6);
+  return std::pow(10.0, w_db / 20.0);
+}
+
+static double smoothing_coeff(double fc, int step, double tau_min, double tau_100) {
+  // earmodel.c:627-635
+  const double tau = tau_min + 100.0 / fc * (tau_100 - tau_min);
+  return std::exp(step / (-48000.0 * tau));
+}
+
+static void fill_common_bands(BandTables& t, const std::vector<double>& fc, int step, double loudness_scale,
+                              double tau_min, double tau_100) {
+  t.bands = static_cast<int>(fc.size());
+  t.step = step;
+  t.deriv_factor = kFs / step;
+  for (int i = 0; i < t.bands; ++i) {
+    const double f = fc[i];
+    t.fc[i] = f;
+    t.internal_noise[i] = std::pow(10.0, 0.4 * 0.364 * std::pow(f / 1000.0, -0.8));
+    t.noise_pow03[i] = std::pow(t.internal_noise[i], 0.3);
+    t.exc_threshold[i] = std::pow(10.0, 0.364 * std::pow(f / 1000.0, -0.8));
+    t.threshold[i] =
+        std::pow(10.0, 0.1 * (-2.0 - 2.05 * std::atan(f / 4000.0) - 0.75 * std::atan(f / 1600.0 * f / 1600.0)));
+    t.loud_factor[i] = loudness_scale * std::pow(t.exc_threshold[i] / (1e4 * t.threshold[i]), 0.23);
+    t.ear_tc[i] = smoothing_coeff(f, step, tau_min, tau_100);
+    t.adapt_tc[i] = smoothing_coeff(f, step, 0.008, 0.05);  // leveladapter.c:205, modpatt.c:185
+  }
+  // neutral padding so that idle lanes never produce NaN/Inf
+  for (int i = t.bands; i < kBandStride; ++i) {
+    t.fc[i] = 1000.0;
+    t.internal_noise[i] = 1.0;
+    t.noise_pow03[i] = 1.0;
+    t.exc_threshold[i] = 1.0;
+    t.threshold[i] = 0.5;
+    t.loud_factor[i] = 0.0;
+    t.ear_tc[i] = 0.0;
+    t.adapt_tc[i] = 0.0;
+  }
+}
+
+// Reference do_spreading (fftearmodel.c:637-676) evaluated on an all-ones
+// pattern; only used to derive the normalisation table.
+static void spread_reference_order(const BandTables& t, const std::vector<double>& aUC, const std::vector<double>& pp,
+                                   std::vector<double>& e2) {
+  const int nb = t.bands;
+  std::vector<double> up(nb), en(nb);
+  for (int i = 0; i < nb; ++i) {
+    const double a = aUC[i] * std::pow(pp[i], 0.2 * t.delta_z);
+    const double giu = (1.0 - std::pow(a, nb - i)) / (1.0 - a);
+    const double e = pp[i] / (t.gIL[i] + giu - 1.0);
+    up[i] = std::pow(a, 0.4);
+    en[i] = std::pow(e, 0.4);
+  }
+  e2.assign(nb, 0.0);
+  e2[nb - 1] = en[nb - 1];
+  for (int i = nb - 1; i > 0; --i) e2[i - 1] = t.aLe * e2[i] + en[i - 1];
+  for (int i = 0; i < nb - 1; ++i) {
+    double r = en[i];
+    for (int j = i + 1; j < nb; ++j) {
+      r *= up[i];
+      e2[j] += r;
+    }
+  }
+  for (int i = 0; i < nb; ++i) e2[i] = std::pow(e2[i], 2.5);
+}
+
+void build_fft_band_tables(int bands, BandTables& t) {
+  std::memset(&t, 0, sizeof t);
+  const int n = kFrame;
+  t.delta_z = 27.0 / (bands - 1);
+  t.dz02 = 0.2 * t.delta_z;
+  const double a_l = std::pow(10.0, -2.7 * t.delta_z);  // 1/a_L
+  t.aLe = std::pow(a_l, 0.4);
+  const double z_lo = 7.0 * std::asinh(80.0 / 650.0);
+  const double z_hi = 7.0 * std::asinh(18000.0 / 650.0);
+  std::vector<double> fc(bands), aUC(bands);
+  for (int i = 0; i < bands; ++i) {
+    const double zl = z_lo + i * t.delta_z;
+    const double zu = std::fmin(z_hi, z_lo + (i + 1) * t.delta_z);
+    const double fl = 650.0 * std::sinh(zl / 7.0);
+    const double fu = 650.0 * std::sinh(zu / 7.0);
+    fc[i] = 650.0 * std::sinh((zl + zu) / 2.0 / 7.0);
+    t.lo[i] = static_cast<int>(std::round(fl / kFs * n));
+    t.hi[i] = static_cast<int>(std::round(fu / kFs * n));
+    // fraction of the edge bins that falls inside the band (Kabal 2.6)
+    double edge = (2 * t.lo[i] + 1) / 2.0 * kFs / n;
+    if (edge > fu) edge = fu;
+    t.wlo[i] = (edge - fl) * n / kFs;
+    if (t.lo[i] == t.hi[i]) {
+      t.whi[i] = 0.0;
+    } else {
+      edge = (2 * t.hi[i] - 1) / 2.0 * kFs / n;
+      t.whi[i] = (fu - edge) * n / kFs;
+    }
+    aUC[i] = std::pow(10.0, (-2.4 - 23.0 / fc[i]) * t.delta_z);
+    t.ln_aUC[i] = std::log(aUC[i]);
+    t.gIL[i] = (1.0 - std::pow(a_l, i + 1)) / (1.0 - a_l);
+    t.mask_diff[i] = std::pow(10.0, (i * t.delta_z <= 12.0 ? 3.0 : 0.25 * i * t.delta_z) / 10.0);
+  }
+  fill_common_bands(t, fc, n / 2, 1.07664, 0.008, 0.030);  // fftearmodel.c:53,224-228
+  std::vector<double> ones(bands, 1.0), norm;
+  spread_reference_order(t, aUC, ones, norm);
+  for (int i = 0; i < bands; ++i) t.inv_spread_norm[i] = 1.0 / norm[i];
+  for (int i = bands; i < kBandStride; ++i) {
+    t.lo[i] = t.hi[i] = 0;
+    t.wlo[i] = t.whi[i] = 0.0;
+    t.ln_aUC[i] = -1.0;
+    t.gIL[i] = 1.0;
+    t.inv_spread_norm[i] = 0.0;
+    t.mask_diff[i] = 1.0;
+  }
+}
+
+void build_fb_band_tables(BandTables& t, FbTables& fb) {
+  std::memset(&t, 0, sizeof t);
+  std::memset(&fb, 0, sizeof fb);
+  static const int kLen[kFbBands] = {1456, 1438, 1406, 1362, 1308, 1244, 1176, 1104, 1030, 956, 884, 814, 748, 686,
+                                     626,  570,  520,  472,  430,  390,  354,  320,  290,  262, 238, 214, 194, 176,
+                                     158,  144,  130,  118,  106,  96,   86,   78,   70,   64,  58,  52};
+  std::vector<double> fc(kFbBands);
+  int off = 0;
+  for (int b = 0; b < kFbBands; ++b) {
+    // Kabal (36)-(37) centre frequencies, fbearmodel.c:201-204
+    fc[b] = std::sinh(std::asinh(50.0 / 650.0) + b * (std::asinh(18000.0 / 650.0) - std::asinh(50.0 / 650.0)) / 39.0) *
+            650.0;
+    const int len = kLen[b];
+    const double wt = ear_weight_db_to_lin(fc[b]);
+    fb.flen[b] = len;
+    fb.delay[b] = 1 + (kLen[0] - len) / 2;
+    fb.coef_off[b] = off;
+    for (int k = 0; k <= len / 2; ++k) {
+      const double s = std::sin(kPi * k / len);
+      const double win = 4.0 / len * s * s * wt;
+      const double ph = 2 * kPi * fc[b] * (k - len / 2.0) / 48000.0;
+      fb.h_re[off + k] = win * std::cos(ph);
+      fb.h_im[off + k] = win * std::sin(ph);
+    }
+    off += len / 2 + 1;
+  }
+  for (int k = 0; k < 6; ++k) {
+    const double c = std::cos(kPi * (k - 5.0) / 12.0);
+    fb.back_mask[k] = c * c * 0.9761 / 6.0;
+  }
+  fill_common_bands(t, fc, kFbFrame, 1.26539, 0.004, 0.020);  // fbearmodel.c:171-177
+  t.delta_z = 0.0;
+}
+
+void build_common_tables(CommonTables& c) {
+  const int n = kFrame;
+  for (int k = 0; k < n; ++k) {
+    c.hann[k] = std::sqrt(8.0 / 3.0) * 0.5 * (1.0 - std::cos(2 * kPi * k / (n - 1)));
+    c.tw_re[k] = std::cos(2 * kPi * k / n);
+    c.tw_im[k] = -std::sin(2 * kPi * k / n);
+  }
+  // exact values on the axes keep the transform of symmetric inputs clean
+  c.tw_re[0] = 1.0;  c.tw_im[0] = 0.0;
+  c.tw_re[n / 4] = 0.0;  c.tw_im[n / 4] = -1.0;
+  c.tw_re[n / 2] = -1.0;  c.tw_im[n / 2] = 0.0;
+  c.tw_re[3 * n / 4] = 0.0;  c.tw_im[3 * n / 4] = 1.0;
+  for (int k = 0; k <= n / 2; ++k) {
+    const double w = ear_weight_db_to_lin(static_cast<double>(k) * kFs / n);
+    c.ear_w2[k] = w * w;
+  }
+  for (int i = 0; i < 256; ++i)  // CENTER_EHS_CORRELATION_WINDOW 0
+    c.ehs_window[i] = 0.81649658092773 * (1.0 - std::cos(2 * kPi * i / 255.0)) / 256.0;
+}
+
+double fft_level_factor(double level_db) {
+  // fftearmodel.c:312-313
+  const double gamma = 0.84971762641205;
+  const double g = gamma / 4 * (kFrame - 1);
+  return std::pow(10.0, level_db / 10.0) / (8.0 / 3.0 * g * g);
+}
+
+double fb_level_factor(double level_db) { return std::pow(10.0, level_db / 20.0); }  // fbearmodel.c:252-253
+
+}  // namespace peaq

@@ -1,0 +1,157 @@
+/* peaq_amd.h -- C ABI of the MI355X-native PEAQ engine (libpeaq_amd.so).
+ *
+ * This is the drop-in boundary of SURVEY.md 8(b): everything the `peaq`
+ * GStreamer element of HSU-ANT/gstpeaq calls below its adapters -- ear models,
+ * level/pattern adaptation, modulation patterns, MOV calculators, MOV
+ * accumulators and the neural network (reference src/{fftearmodel,fbearmodel,
+ * earmodel,leveladapter,modpatt,movs,movaccum,nn}.c) -- is replaced by batched
+ * HIP kernels for gfx950 behind the entry points declared here.  Plain C,
+ * plain pointers and sizes; no GLib, GStreamer or torch types.
+ *
+ * Two ways in:
+ *   session API  one handle per element instance / per (ref,test) stream; the
+ *                element's pad_chain / change_state / get_property call it
+ *                (gstpeaq_amd/gst/gstpeaq_amd.c is that element).
+ *   batch API    N whole (ref,test) pairs resident in device memory, the shape
+ *                of BASELINE.json configs 2-4.
+ *
+ * All functions return PEAQ_OK (0) or a negative error; peaq_last_error()
+ * gives the message of the calling thread's last failure.  The reference's DSP
+ * calls cannot fail (SURVEY.md 8(b) "error convention"); device/allocation
+ * errors are new and map to GST_FLOW_ERROR in the element.
+ */
+#ifndef PEAQ_AMD_H
+#define PEAQ_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PEAQ_OK            0
+#define PEAQ_ERR_ARG      -1   /* bad argument */
+#define PEAQ_ERR_DEVICE   -2   /* HIP runtime error (no GPU, launch failure, ...) */
+#define PEAQ_ERR_NOMEM    -3
+#define PEAQ_ERR_STATE    -4   /* call not valid in the handle's current state */
+
+#define PEAQ_MOVS_BASIC     11  /* order = enum _MovBasic, gstpeaq.c:95-108 */
+#define PEAQ_MOVS_ADVANCED   5  /* order = enum _MovAdvanced, gstpeaq.c:86-93 */
+
+/* One result record per pair (batch API) -- 16 doubles.
+ * movs[] holds 11 (basic) or 5 (advanced) values, the rest is 0. */
+typedef struct {
+  double movs[PEAQ_MOVS_BASIC];
+  double di;          /* peaq_calculate_di_basic/_advanced, nn.c:187,304 */
+  double odg;         /* peaq_calculate_odg, nn.c:372 */
+  double totalsnr;    /* element property "totalsnr", gstpeaq.c:493-497 */
+  double frames;      /* FFT frame-pairs processed (frame_counter, gstpeaq.c:920) */
+  double fb_blocks;   /* filter-bank blocks processed (advanced; gstpeaq.c:1009) */
+} peaq_result;
+
+const char *peaq_last_error (void);
+/* "x.y.z gfx950" */
+const char *peaq_version (void);
+
+/* ---- device context -------------------------------------------------------
+ * Owns the constant tables in HBM (Hann window, ear weights, band tables,
+ * twiddles, filter-bank impulse responses -- what the reference builds in
+ * fftearmodel.c:160-173,240-257,693-788, fbearmodel.c:188-225,
+ * earmodel.c:279-323) for one GPU.  Thread-safe; create one per process/GPU. */
+typedef struct peaq_ctx peaq_ctx;
+int peaq_ctx_create (int device_ordinal, peaq_ctx **out);
+void peaq_ctx_destroy (peaq_ctx *ctx);
+int peaq_ctx_device (const peaq_ctx *ctx);
+
+/* ---- session API ------------------------------------------------------------
+ * Replaces, per element instance: g_object_new(PEAQ_TYPE_FFTEARMODEL /
+ * _FILTERBANKEARMODEL) gstpeaq.c:364-365, peaq_movaccum_new x11 :376,
+ * "number-of-bands"/"playback-level" :481-526, peaq_movaccum_set_mode :528-557,
+ * _set_channels :580-584, alloc_per_channel_data :442-473.
+ * `channels` is what set_caps learns (1 or 2); changing caps or the `advanced`
+ * property means destroying and re-creating the session, as the reference
+ * re-allocates all per-channel state there (gstpeaq.c:519,559,575,586). */
+typedef struct peaq_session peaq_session;
+int peaq_session_create (peaq_ctx *ctx, int advanced, int channels,
+                         double playback_level_db, peaq_session **out);
+void peaq_session_destroy (peaq_session *s);
+
+/* pad_chain (gstpeaq.c:614-661): append interleaved F32 samples
+ * (n = samples per channel) to the ref (pad 0) or test (pad 1) adapter and
+ * process every frame that both adapters now hold (do_processing :596-611:
+ * FFT frames 2048/1024; advanced additionally filter-bank blocks 192/192).
+ * The data is copied before the call returns (SURVEY.md 8(b) ownership).
+ * Processing is asynchronous on the session's HIP stream. */
+int peaq_session_push (peaq_session *s, int pad, const float *interleaved, size_t n);
+
+/* change_state PAUSED->READY (gstpeaq.c:764-776): one zero-padded frame from
+ * whatever is left in the adapters (do_flush :716-745); leftovers may differ
+ * between ref and test. */
+int peaq_session_flush (peaq_session *s);
+
+/* get_property "di"/"odg" (gstpeaq.c:484-492 -> calculate_di_* :1013-1063,
+ * calculate_odg :1066-1078): callable at any time, idempotent.  movs receives
+ * 11 or 5 values (may be NULL).  NaN-on-empty-accumulator behaviour of the
+ * reference is preserved. */
+int peaq_session_results (peaq_session *s, peaq_result *out);
+
+/* explicit reset (the reference never resets, gstpeaq.c:357-361; the element
+ * does not call this) */
+int peaq_session_reset (peaq_session *s);
+
+/* ---- batch API ------------------------------------------------------------
+ * n_pairs whole pairs, inputs already in device memory as interleaved F32
+ * [pair][sample][channel] with a fixed stride of `pair_stride` samples between
+ * pairs.  n_ref / n_test give each pair's length in samples per channel (host
+ * arrays of n_pairs entries; NULL = every pair has n_uniform samples).  Each
+ * pair is framed and flushed exactly as one element run would be (full frames
+ * + one zero-padded frame).  d_results: device array of n_pairs peaq_result.
+ * `stream` is a hipStream_t (NULL = default stream); the call enqueues work
+ * and returns, results are valid after the stream is synchronised. */
+int peaq_batch_run (peaq_ctx *ctx, int advanced, int channels, double playback_level_db,
+                    int n_pairs, const float *d_ref, const float *d_test, size_t pair_stride,
+                    const uint32_t *n_ref, const uint32_t *n_test, uint32_t n_uniform,
+                    peaq_result *d_results, void *stream);
+
+/* Scratch the batch path needs for a given shape, in bytes (it is allocated
+ * lazily inside the context and reused across calls). */
+size_t peaq_batch_workspace_bytes (int advanced, int channels, int n_pairs, uint32_t n_max);
+
+/* Timing of the last peaq_batch_run on this context, measured with HIP events
+ * on `stream`: total milliseconds, and milliseconds / launch count of the
+ * dominant kernel (the FFT ear-model front end).  Valid after the stream has
+ * been synchronised.  Used by bench.py for the roofline line. */
+typedef struct {
+  float total_ms;
+  float frontend_ms;      /* sum over launches of the front-end kernel */
+  int   frontend_launches;
+  float backend_ms;
+  int   backend_launches;
+  float fb_ms;            /* advanced: filter-bank kernels */
+  int   fb_launches;
+} peaq_batch_timing;
+int peaq_batch_last_timing (peaq_ctx *ctx, peaq_batch_timing *out);
+
+/* ---- synthetic workload (include/peaq_synth.h on the device) -------------
+ * Fills d_ref/d_test [n_pairs][pair_stride][channels] with the seeded pairs
+ * seed0 .. seed0+n_pairs-1, n_samples each.  Benchmark / test utility. */
+int peaq_synth_fill (peaq_ctx *ctx, uint32_t seed0, int n_pairs, int channels,
+                     uint32_t n_samples, size_t pair_stride,
+                     float *d_ref, float *d_test, void *stream);
+
+/* ---- stage-level access for parity tests ----------------------------------
+ * Runs only the stateless front end (window, FFT, power spectra, band
+ * grouping, spreading, per-frame MOV ingredients) on ONE pair resident in
+ * device memory and copies the per-frame records to host memory:
+ *   out[frame][channel][PEAQ_DEBUG_RECORD_DOUBLES]
+ * see DESIGN.md "frame record" for the layout. */
+#define PEAQ_DEBUG_RECORD_DOUBLES 576
+int peaq_debug_frontend (peaq_ctx *ctx, int bands, int channels, double playback_level_db,
+                         const float *d_ref, const float *d_test, uint32_t n_ref, uint32_t n_test,
+                         int n_frames, double *host_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEAQ_AMD_H */

@@ -856,32 +856,54 @@ mov_moddiff (orc_session *s, const orc_bands *b, orc_movaccum *a1, orc_movaccum 
 }
 
 static void
-mov_bandwidth (orc_session *s, orc_movaccum *aref, orc_movaccum *atest)
+bandwidth_of_frame (const double *pr, const double *pt, int *bw_ref_out, int *bw_test_out)
 {
-  /* movs.c:776-809: unweighted power spectrum */
-  int c, i;
-  for (c = 0; c < aref->channels; c++) {
-    const double *pr = s->ref_fft_st[c].power, *pt = s->test_fft_st[c].power;
-    double thr = pt[921];
-    int bw_ref = 0, bw_test = 0;
-    for (i = 922; i < 1024; i++)
-      if (pt[i] >= thr)
-        thr = pt[i];
-    for (i = 921; i > 0; i--)
-      if (pr[i - 1] > 10. * thr) {
-        bw_ref = i;
+  /* movs.c:783-805: unweighted power spectrum */
+  double thr = pt[921];
+  int bw_ref = 0, bw_test = 0, i;
+  for (i = 922; i < 1024; i++)
+    if (pt[i] >= thr)
+      thr = pt[i];
+  for (i = 921; i > 0; i--)
+    if (pr[i - 1] > 10. * thr) {
+      bw_ref = i;
+      break;
+    }
+  if (bw_ref > 346) {
+    for (i = bw_ref; i > 0; i--)
+      if (pt[i - 1] >= 3.16227766016838 * thr) {
+        bw_test = i;
         break;
       }
+  }
+  *bw_ref_out = bw_ref;
+  *bw_test_out = bw_test;
+}
+
+static void
+mov_bandwidth (orc_session *s, orc_movaccum *aref, orc_movaccum *atest)
+{
+  /* movs.c:776-809 */
+  int c;
+  for (c = 0; c < aref->channels; c++) {
+    int bw_ref, bw_test;
+    bandwidth_of_frame (s->ref_fft_st[c].power, s->test_fft_st[c].power, &bw_ref, &bw_test);
     if (bw_ref > 346) {
-      for (i = bw_ref; i > 0; i--)
-        if (pt[i - 1] >= 3.16227766016838 * thr) {
-          bw_test = i;
-          break;
-        }
       orc_acc_add (aref, c, bw_ref, 1.);
       orc_acc_add (atest, c, bw_test, 1.);
     }
   }
+}
+
+static void
+noise_in_bands (const orc_fftmodel *m, const double *wr, const double *wt, double *nib)
+{
+  /* movs.c:992-1000 */
+  double noise[ORC_FFT_BINS];
+  int i;
+  for (i = 0; i < ORC_FFT_BINS; i++)
+    noise[i] = wr[i] - 2 * sqrt (wr[i] * wt[i]) + wt[i];
+  orc_fftmodel_group (m, noise, nib);
 }
 
 static void
@@ -892,10 +914,8 @@ mov_nmr (orc_session *s, orc_movaccum *anmr, orc_movaccum *arel)
   int c, i, nb = m->b.bands;
   for (c = 0; c < anmr->channels; c++) {
     const double *wr = s->ref_fft_st[c].weighted, *wt = s->test_fft_st[c].weighted;
-    double noise[ORC_FFT_BINS], nib[ORC_MAXBANDS], nmr = 0., nmr_max = 0.;
-    for (i = 0; i < ORC_FFT_BINS; i++)
-      noise[i] = wr[i] - 2 * sqrt (wr[i] * wt[i]) + wt[i];
-    orc_fftmodel_group (m, noise, nib);
+    double nib[ORC_MAXBANDS], nmr = 0., nmr_max = 0.;
+    noise_in_bands (m, wr, wt, nib);
     for (i = 0; i < nb; i++) {
       double mask = s->ref_fft_st[c].excitation[i] / m->mask_diff[i];
       double r = nib[i] / mask;
@@ -946,60 +966,66 @@ mov_prob_detect (orc_session *s, orc_movaccum *aadb, orc_movaccum *amfpd)
   orc_acc_add (amfpd, 0, p_bin, 1.);
 }
 
+static double
+ehs_of_frame (const double *fr, const double *ft)
+{
+  /* movs.c:1279-1315 (do_xcorr), :1383-1441; settings.h: window not centred,
+   * mean removed before windowing */
+  enum { LAG = 256 };
+  double d[2 * LAG], t[2 * LAG], corr[2 * LAG];
+  double f1r[LAG + 1], f1i[LAG + 1], f2r[LAG + 1], f2i[LAG + 1];
+  double cr[LAG / 2 + 1], ci[LAG / 2 + 1];
+  double d0, dk, cavg = 0., ehs = 0., prev;
+  int i;
+  for (i = 0; i < 2 * LAG; i++)
+    d[i] = (fr[i] == 0. && ft[i] == 0.) ? 0. : log (ft[i] / fr[i]);
+  /* c[l] = sum_{k<256} d[k] d[k+l] through 512-point DFTs */
+  memcpy (t, d, sizeof t);
+  real_dft (t, 2 * LAG, f1r, f1i);
+  memset (t + LAG, 0, LAG * sizeof (double));
+  real_dft (t, 2 * LAG, f2r, f2i);
+  for (i = 0; i <= LAG; i++) {
+    double r = (f1r[i] * f2r[i] + f1i[i] * f2i[i]) / (2 * LAG);
+    double q = (f2r[i] * f1i[i] - f1r[i] * f2i[i]) / (2 * LAG);
+    f1r[i] = r;
+    f1i[i] = q;
+  }
+  real_idft (f1r, f1i, 2 * LAG, corr);
+  d0 = corr[0];
+  dk = d0;
+  for (i = 0; i < LAG; i++) {
+    corr[i] /= sqrt (d0 * dk);
+    cavg += corr[i];
+    dk += d[i + LAG] * d[i + LAG] - d[i] * d[i];
+  }
+  cavg /= LAG;
+  for (i = 0; i < LAG; i++) {
+    double w = 0.81649658092773 * (1 - cos (2 * M_PI * i / (LAG - 1))) / LAG;
+    corr[i] = (corr[i] - cavg) * w;
+  }
+  real_dft (corr, LAG, cr, ci);
+  prev = cr[0] * cr[0] + ci[0] * ci[0];
+  for (i = 1; i <= LAG / 2; i++) {
+    double cur = cr[i] * cr[i] + ci[i] * ci[i];
+    if (cur > prev && cur > ehs)
+      ehs = cur;
+    prev = cur;
+  }
+  return ehs;
+}
+
 static void
 mov_ehs (orc_session *s, orc_movaccum *aehs)
 {
-  /* movs.c:1279-1315 (do_xcorr), :1346-1443; settings.h: window not centred,
-   * mean removed before windowing */
-  enum { LAG = 256 };
-  int c, i, valid = 0;
+  /* movs.c:1346-1443 */
+  int c, valid = 0;
   for (c = 0; c < aehs->channels; c++)
     if (s->ref_fft_st[c].energy_reached || s->test_fft_st[c].energy_reached)
       valid = 1;
   if (!valid)
     return;
-  for (c = 0; c < aehs->channels; c++) {
-    const double *fr = s->ref_fft_st[c].weighted, *ft = s->test_fft_st[c].weighted;
-    double d[2 * LAG], t[2 * LAG], corr[2 * LAG];
-    double f1r[LAG + 1], f1i[LAG + 1], f2r[LAG + 1], f2i[LAG + 1];
-    double cr[LAG / 2 + 1], ci[LAG / 2 + 1];
-    double d0, dk, cavg = 0., ehs = 0., prev;
-    for (i = 0; i < 2 * LAG; i++)
-      d[i] = (fr[i] == 0. && ft[i] == 0.) ? 0. : log (ft[i] / fr[i]);
-    /* c[l] = sum_{k<256} d[k] d[k+l] through 512-point DFTs */
-    memcpy (t, d, sizeof t);
-    real_dft (t, 2 * LAG, f1r, f1i);
-    memset (t + LAG, 0, LAG * sizeof (double));
-    real_dft (t, 2 * LAG, f2r, f2i);
-    for (i = 0; i <= LAG; i++) {
-      double r = (f1r[i] * f2r[i] + f1i[i] * f2i[i]) / (2 * LAG);
-      double q = (f2r[i] * f1i[i] - f1r[i] * f2i[i]) / (2 * LAG);
-      f1r[i] = r;
-      f1i[i] = q;
-    }
-    real_idft (f1r, f1i, 2 * LAG, corr);
-    d0 = corr[0];
-    dk = d0;
-    for (i = 0; i < LAG; i++) {
-      corr[i] /= sqrt (d0 * dk);
-      cavg += corr[i];
-      dk += d[i + LAG] * d[i + LAG] - d[i] * d[i];
-    }
-    cavg /= LAG;
-    for (i = 0; i < LAG; i++) {
-      double w = 0.81649658092773 * (1 - cos (2 * M_PI * i / (LAG - 1))) / LAG;
-      corr[i] = (corr[i] - cavg) * w;
-    }
-    real_dft (corr, LAG, cr, ci);
-    prev = cr[0] * cr[0] + ci[0] * ci[0];
-    for (i = 1; i <= LAG / 2; i++) {
-      double cur = cr[i] * cr[i] + ci[i] * ci[i];
-      if (cur > prev && cur > ehs)
-        ehs = cur;
-      prev = cur;
-    }
-    orc_acc_add (aehs, c, 1000. * ehs, 1.);
-  }
+  for (c = 0; c < aehs->channels; c++)
+    orc_acc_add (aehs, c, 1000. * ehs_of_frame (s->ref_fft_st[c].weighted, s->test_fft_st[c].weighted), 1.);
 }
 
 static void
@@ -1421,4 +1447,65 @@ orc_flat_tables (int bands, double *out)
     memcpy (out + 7 * bands, fm->mask_diff, n);
   }
   free (fm);
+}
+
+/* Per-frame "front-end records" of one pair in the layout of the HIP front end
+ * (gstpeaq_amd/csrc/peaq_device.h kRec*): out[frame][channel][576].  Stage-level
+ * parity checks of the GPU path compare against this. */
+void
+orc_flat_frontend_records (int bands, int channels, double level_db, const float *ref, size_t n_ref,
+                           const float *test, size_t n_test, int n_frames, double *out)
+{
+  orc_fftmodel *m = (orc_fftmodel *) malloc (sizeof *m);
+  orc_fftstate *sr = (orc_fftstate *) calloc (2, sizeof *sr), *st = (orc_fftstate *) calloc (2, sizeof *st);
+  float *fr = (float *) malloc (ORC_FFT_FRAME * channels * sizeof (float));
+  float *ft = (float *) malloc (ORC_FFT_FRAME * channels * sizeof (float));
+  float ch[ORC_FFT_FRAME];
+  int f, c, i;
+  orc_fftmodel_init (m, bands, level_db);
+  for (f = 0; f < n_frames; f++) {
+    size_t s0 = (size_t) f * 1024;
+    for (i = 0; i < ORC_FFT_FRAME * channels; i++) {
+      size_t smp = s0 + i / channels;
+      fr[i] = smp < n_ref ? ref[s0 * channels + i] : 0.f;
+      ft[i] = smp < n_test ? test[s0 * channels + i] : 0.f;
+    }
+    for (c = 0; c < channels; c++) {
+      double *rec = out + ((size_t) f * channels + c) * 576;
+      int bw_ref, bw_test, above_c;
+      double se = 0., ne = 0.;
+      memset (rec, 0, 576 * sizeof (double));
+      deinterleave (fr, ORC_FFT_FRAME, channels, c, ch);
+      above_c = frame_above_threshold (ch, ORC_FFT_FRAME, 1);
+      orc_fftmodel_process (m, &sr[c], ch);
+      deinterleave (ft, ORC_FFT_FRAME, channels, c, ch);
+      orc_fftmodel_process (m, &st[c], ch);
+      for (i = 0; i < bands; i++) {
+        rec[0 * 112 + i] = sr[c].unsmeared[i];
+        rec[1 * 112 + i] = st[c].unsmeared[i];
+        rec[2 * 112 + i] = pow (sr[c].unsmeared[i], 0.3);
+        rec[3 * 112 + i] = pow (st[c].unsmeared[i], 0.3);
+      }
+      noise_in_bands (m, sr[c].weighted, st[c].weighted, rec + 4 * 112);
+      bandwidth_of_frame (sr[c].power, st[c].power, &bw_ref, &bw_test);
+      rec[560] = bw_ref;
+      rec[561] = bw_test;
+      rec[562] = ehs_of_frame (sr[c].weighted, st[c].weighted);
+      rec[563] = above_c | (sr[c].energy_reached << 1);
+      rec[564] = st[c].energy_reached << 1;
+      for (i = 0; i < 1024; i++) {
+        float a = fr[i * channels + c], b = ft[i * channels + c];
+        float sq = a * a, df = (a - b) * (a - b);
+        se += sq;
+        ne += df;
+      }
+      rec[565] = se;
+      rec[566] = ne;
+    }
+  }
+  free (m);
+  free (sr);
+  free (st);
+  free (fr);
+  free (ft);
 }

@@ -1,0 +1,153 @@
+"""Parity of the HIP path (through the C ABI of libpeaq_amd.so) with the CPU
+oracle and with the committed outputs of the real reference.  Needs an MI355X:
+run with `-m gpu`.  Tolerances are stated per check; the north-star bar is
+|dODG| <= 0.02, the FP64 device path is held to ~1e-6 and better."""
+import numpy as np
+import pytest
+
+import cases as case_defs
+import oracle_lib as orc
+import synth_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (there is no CPU fallback in the product)")
+    import gpu_common
+    return gpu_common
+
+
+def test_library_reports_version(gpu):
+    import gstpeaq_amd
+    assert b"gfx950" in gstpeaq_amd.load_library().peaq_version()
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_device_synth_matches_header(gpu, channels):
+    """include/peaq_synth.h is bit-identical in gcc, numpy and HIP"""
+    import gstpeaq_amd
+    ref, test = gstpeaq_amd.synth_fill(gpu.ctx(), 3, 3, channels, 30000)
+    for p in range(3):
+        r, t = synth_np.pair(3 + p, channels, 30000)
+        assert np.array_equal(ref[p].cpu().numpy(), r)
+        assert np.array_equal(test[p].cpu().numpy(), t)
+
+
+def oracle_records(bands, ref, test, n_frames):
+    import ctypes as C
+    L = orc.lib()
+    ch = ref.shape[1]
+    out = np.zeros((n_frames, ch, 576))
+    L.orc_flat_frontend_records.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_float), C.c_size_t,
+                                            C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    r = np.ascontiguousarray(ref, dtype=np.float32)
+    t = np.ascontiguousarray(test, dtype=np.float32)
+    L.orc_flat_frontend_records(bands, ch, 92.0, r.ctypes.data_as(C.POINTER(C.c_float)), len(r),
+                                t.ctypes.data_as(C.POINTER(C.c_float)), len(t), n_frames,
+                                out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+@pytest.mark.parametrize("bands", [109, 55])
+@pytest.mark.parametrize("case", [
+    dict(kind="synth", seed=5, channels=1, n=20000),
+    dict(kind="synth", seed=6, channels=2, n=20000, test_trim=900),
+    dict(kind="synth", seed=1, channels=2, n=30000),             # leading digital silence
+    dict(kind="synth", seed=9, channels=2, n=20000, atten_shift=9),   # around the detector thresholds
+    dict(kind="synth", seed=26, channels=2, n=12000, identical=1),
+    dict(kind="ats", wave_ref="saw", wave_test="triangle", n=16384, channels=1),
+], ids=["mono", "stereo-ragged", "lead-silence", "quiet", "identical", "saw-triangle"])
+def test_frontend_records_match_oracle(gpu, bands, case):
+    """stage-level: every field of the per-frame record (unsmeared excitation,
+    loudness^0.3, noise in bands, bandwidths, EHS, flags, energies)"""
+    import torch
+    import gstpeaq_amd
+    ref, test = case_defs.make_inputs(case)
+    n = min(len(ref), len(test))
+    n_frames = (n - 2048) // 1024 + 2           # all full frames + the flush frame
+    got = gstpeaq_amd.debug_frontend(gpu.ctx(), bands, torch.from_numpy(ref).cuda(), torch.from_numpy(test).cuda(),
+                                     n_frames)
+    exp = oracle_records(bands, ref, test, n_frames)
+    for name, lo in (("unsm_ref", 0), ("unsm_test", 112), ("loud_ref", 224), ("loud_test", 336), ("noise", 448)):
+        np.testing.assert_allclose(got[:, :, lo:lo + bands], exp[:, :, lo:lo + bands], rtol=2e-10, atol=0,
+                                   err_msg=name)
+    assert np.array_equal(got[:, :, 560:562], exp[:, :, 560:562]), "bandwidths"
+    assert np.array_equal(got[:, :, 563:565], exp[:, :, 563:565]), "flags"
+    # EHS: the oracle goes through 512-point FFTs like the reference, the kernel sums directly
+    assert np.array_equal(np.isnan(got[:, :, 562]), np.isnan(exp[:, :, 562]))
+    np.testing.assert_allclose(got[:, :, 562], exp[:, :, 562], rtol=1e-7, atol=1e-13, err_msg="ehs")
+    np.testing.assert_allclose(got[:, :, 565:567], exp[:, :, 565:567], rtol=1e-12, atol=0, err_msg="energies")
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_batch_basic_matches_reference_goldens(gpu, channels):
+    """every basic-mode end-to-end case of tests/golden/ref_e2e.json (outputs of the
+    REAL reference element), ragged lengths in one batch call"""
+    recs = [r for r in gpu.e2e_records(0) if r["case"]["channels"] == channels]
+    inputs = [case_defs.make_inputs(r["case"]) for r in recs]
+    got = gpu.run_batch(inputs, 0, channels)
+    worst = 0.0
+    for g, rec in zip(got, recs):
+        gpu.compare_result(g, rec, rtol=1e-7, atol=1e-9, odg_atol=1e-6)
+        if not np.isnan(float(rec["odg"])):
+            worst = max(worst, abs(g["odg"] - float(rec["odg"])))
+    print(f"max |dODG| vs reference over {len(recs)} cases: {worst:.3e}")
+
+
+def test_reference_odg_regression_strings_on_gpu(gpu):
+    # runtest-1.0.sh:18,28
+    a = case_defs.make_inputs(dict(kind="ats", wave_ref="sine", wave_test="sine", n=131072, channels=1))
+    b = case_defs.make_inputs(dict(kind="ats", wave_ref="saw", wave_test="triangle", n=131072, channels=1))
+    got = gpu.run_batch([a, b], 0, 1)
+    assert "%.3f" % got[0]["odg"] == "0.171"
+    assert "%.3f" % got[1]["odg"] == "-2.007"
+
+
+def test_batch_matches_oracle_on_seeded_pairs(gpu):
+    """64 seeded stereo pairs generated ON the device vs the CPU oracle on the same bits"""
+    import gstpeaq_amd
+    n, seed0, pairs = 96000, 1000, 64
+    ref, test = gstpeaq_amd.synth_fill(gpu.ctx(), seed0, pairs, 2, n)
+    got = gstpeaq_amd.batch_run(gpu.ctx(), 0, ref, test)
+    worst = 0.0
+    for p in range(0, pairs, 4):                      # the oracle needs ~0.1 s per pair
+        r, t = synth_np.pair(seed0 + p, 2, n)
+        e = orc.run_pair(0, r, t)
+        np.testing.assert_allclose(got[p]["movs"], e["movs"], rtol=1e-7, atol=1e-9)
+        worst = max(worst, abs(got[p]["odg"] - e["odg"]))
+    assert worst < 1e-6
+    print(f"max |dODG| vs oracle: {worst:.3e}")
+
+
+def test_session_streaming_equals_batch(gpu):
+    """pad_chain delivers arbitrary buffer sizes on either pad (gstpeaq.c:614-661)"""
+    import gstpeaq_amd
+    case = dict(kind="synth", seed=3, channels=2, n=150000, test_trim=1234)
+    ref, test = case_defs.make_inputs(case)
+    whole = gpu.run_batch([(ref, test)], 0, 2)[0]
+    s = gstpeaq_amd.Session(gpu.ctx(), 0, 2)
+    rng = np.random.default_rng(1)
+    pr = pt = 0
+    mid = None
+    while pr < len(ref) or pt < len(test):
+        if pr < len(ref):
+            k = int(rng.integers(1, 9000))
+            s.push_ref(ref[pr:pr + k])
+            pr += k
+        if pt < len(test):
+            k = int(rng.integers(1, 9000))
+            s.push_test(test[pt:pt + k])
+            pt += k
+        if mid is None and pr > 70000:
+            mid = s.results()                          # results are readable mid-stream
+    s.flush()
+    got = s.results()
+    assert mid["frames"] > 0 and mid["frames"] < got["frames"]
+    assert got["frames"] == whole["frames"]
+    assert np.array_equal(got["movs"], whole["movs"]) and got["odg"] == whole["odg"]
+    assert s.results()["odg"] == got["odg"]            # idempotent
+    s.close()
