@@ -11,6 +11,7 @@
  *   ref_harness pair  ADV CH REF.f32 TEST.f32     raw interleaved F32LE files
  *   ref_harness synth ADV CH SEED NSAMPLES        include/peaq_synth.h pair
  *   ref_harness launch ADV "<gst-launch fragment feeding peaq.ref / peaq.test>"
+ *   ref_harness time ADV CH SEED0 NPAIRS NSAMPLES  wall-clock of the element on NPAIRS synth pairs
  *   ref_harness fftear BANDS FILE.f32             per-frame ear-model dumps (mono, hop 1024)
  *   ref_harness fbear FILE.f32                    per-block filter-bank dumps (mono, 192)
  * Output: one JSON object on stdout.
@@ -21,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <time.h>
 #include "../include/peaq_synth.h"
 
 GST_PLUGIN_STATIC_DECLARE (peaq);
@@ -97,6 +99,68 @@ run_files (int advanced, int channels, const char *ref, const char *test)
             "filesrc location=%s ! rawaudioparse format=pcm pcm-format=f32le sample-rate=48000 "
             "num-channels=%d ! peaq.test peaq name=peaq", ref, channels, test, channels);
   return run_pipeline (advanced, desc);
+}
+
+static double
+now_s (void)
+{
+  struct timespec t;
+  clock_gettime (CLOCK_MONOTONIC, &t);
+  return t.tv_sec + 1e-9 * t.tv_nsec;
+}
+
+/* CPU baseline: the real element, fed from page-cached raw files; generation of
+ * the inputs is not timed, pipeline construction/teardown is (a few ms). */
+static int
+time_pairs (int advanced, int channels, uint32_t seed0, int n_pairs, uint32_t ns)
+{
+  float *r = malloc ((size_t) ns * channels * 4), *t = malloc ((size_t) ns * channels * 4);
+  char fr[256], ft[256], desc[2048];
+  double total = 0.;
+  unsigned frames = 0;
+  int p, saved_out;
+  snprintf (fr, sizeof fr, "/tmp/refh_%d_r.f32", (int) getpid ());
+  snprintf (ft, sizeof ft, "/tmp/refh_%d_t.f32", (int) getpid ());
+  snprintf (desc, sizeof desc,
+            "filesrc location=%s ! rawaudioparse format=pcm pcm-format=f32le sample-rate=48000 "
+            "num-channels=%d ! peaq.ref "
+            "filesrc location=%s ! rawaudioparse format=pcm pcm-format=f32le sample-rate=48000 "
+            "num-channels=%d ! peaq.test peaq name=peaq", fr, channels, ft, channels);
+  for (p = 0; p < n_pairs; p++) {
+    FILE *f;
+    double t0;
+    GError *err = NULL;
+    GstElement *pipe, *peaq_el;
+    GstBus *bus;
+    GstMessage *msg;
+    double odg;
+    peaq_synth_pair (seed0 + p, channels, ns, r, t);
+    f = fopen (fr, "wb"); fwrite (r, 4, (size_t) ns * channels, f); fclose (f);
+    f = fopen (ft, "wb"); fwrite (t, 4, (size_t) ns * channels, f); fclose (f);
+    t0 = now_s ();
+    pipe = gst_parse_launch (desc, &err);
+    if (!pipe) return 2;
+    peaq_el = gst_bin_get_by_name (GST_BIN (pipe), "peaq");
+    g_object_set (peaq_el, "advanced", advanced, "console-output", FALSE, NULL);
+    gst_element_set_state (pipe, GST_STATE_PLAYING);
+    bus = gst_element_get_bus (pipe);
+    msg = gst_bus_timed_pop_filtered (bus, GST_CLOCK_TIME_NONE, GST_MESSAGE_EOS | GST_MESSAGE_ERROR);
+    if (GST_MESSAGE_TYPE (msg) == GST_MESSAGE_ERROR) return 3;
+    gst_message_unref (msg);
+    gst_object_unref (bus);
+    gst_element_set_state (pipe, GST_STATE_NULL);
+    g_object_get (peaq_el, "odg", &odg, NULL);
+    total += now_s () - t0;
+    frames += GST_PEAQ (peaq_el)->frame_counter;
+    gst_object_unref (peaq_el);
+    gst_object_unref (pipe);
+  }
+  (void) saved_out;
+  remove (fr);
+  remove (ft);
+  printf ("{\"pairs\": %d, \"frame_pairs\": %u, \"seconds\": %.6f, \"frame_pairs_per_s\": %.1f}\n",
+          n_pairs, frames, total, frames / total);
+  return 0;
 }
 
 static float *
@@ -213,6 +277,9 @@ main (int argc, char **argv)
     remove (ft);
     return rc;
   }
+  if (argc >= 7 && !strcmp (argv[1], "time"))
+    return time_pairs (atoi (argv[2]), atoi (argv[3]), (uint32_t) strtoul (argv[4], NULL, 0), atoi (argv[5]),
+                       (uint32_t) strtoul (argv[6], NULL, 0));
   if (argc >= 4 && !strcmp (argv[1], "launch"))
     return run_pipeline (atoi (argv[2]), argv[3]);
   if (argc >= 4 && !strcmp (argv[1], "fftear"))
