@@ -586,6 +586,135 @@ hipError_t launch_backend(const BackendArgs& a, unsigned n_pairs, hipStream_t st
 }
 
 // ---------------------------------------------------------------------------
+// Filter-bank back end of the advanced version (gstpeaq.c:965-1010): 40 bands,
+// one band per lane, blocks of 192 samples in order.
+// ---------------------------------------------------------------------------
+struct FbBackendShared {
+  double pa[2][2][kLdsBands];
+  int gate[2];
+};
+
+__global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
+  __shared__ FbBackendShared sh;
+  constexpr int NB = kFbBands, SLOTS = 1;
+  const int lane = threadIdx.x & 63;
+  const int chan = threadIdx.x >> 6;
+  const int channels = a.channels;
+  const unsigned pair = blockIdx.x;
+  const BandTables* __restrict__ bt = a.bands;
+  const BandLane<NB, SLOTS> bl{lane};
+  PairState* __restrict__ ps = a.state + pair;
+  ChannelState* __restrict__ cs = &ps->ch[chan];
+  const unsigned n_blocks = a.n_blocks ? a.n_blocks[pair] : a.n_blocks_uniform;
+  unsigned b_end = a.block0 + a.blocks_per_launch;
+  if (b_end > n_blocks) b_end = n_blocks;
+  if (a.block0 >= b_end) return;
+
+  const int bb = lane < kBandStride ? lane : 0;
+  double la[6][SLOTS], mdr[3][SLOTS], mdt[3][SLOTS];
+#pragma unroll
+  for (int v = 0; v < 6; ++v) la[v][0] = cs->vec[kLaFiltRef + v][bb];
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {
+    mdr[v][0] = cs->vec[kModPrevRef + v][bb];
+    mdt[v][0] = cs->vec[kModPrevTest + v][bb];
+  }
+  LaneAcc acc;
+  {
+    const int i = lane < kMaxAcc ? lane : 0;
+    acc.load(cs->acc[i], acc_mode(true, i), ps->status[i]);
+  }
+  const bool owns = lane == MA_RMSMOD || lane == MA_NLASYM || lane == MA_LINDIST;
+  unsigned loud_reached = ps->loudness_reached;
+
+  for (unsigned blk = a.block0; blk < b_end; ++blk) {
+    const double* __restrict__ rec0 =
+        a.records + ((size_t)(pair * a.blocks_per_launch + (blk - a.block0)) * channels) * kFbRecDoubles;
+    const double* __restrict__ rec = rec0 + (size_t)chan * kFbRecDoubles;
+    // boundary detector on the 192-sample block, any reference channel (gstpeaq.c:971-979)
+    bool above = rec0[kFbRecFlags] != 0.;
+    if (channels == 2) above = above || rec0[kFbRecDoubles + kFbRecFlags] != 0.;
+    if (owns) acc.set_tentative(!above);
+
+    double ur[SLOTS], ut[SLOTS], er[SLOTS], et[SLOTS], lr[SLOTS], lt[SLOTS];
+    const int lb = lane < NB ? lane : 0;
+    ur[0] = rec[kFbRecUnsmRef + lb];
+    ut[0] = rec[kFbRecUnsmTest + lb];
+    er[0] = rec[kFbRecExcRef + lb];
+    et[0] = rec[kFbRecExcTest + lb];
+    lr[0] = pow(ur[0], 0.3);                         // modpatt.c:235
+    lt[0] = pow(ut[0], 0.3);
+    double ad_ref[SLOTS], ad_test[SLOTS], mr[SLOTS], mt[SLOTS];
+    level_adapt<NB, SLOTS>(bl, bt, er, et, la, &sh.pa[chan][0][0], ad_ref, ad_test);
+    modulation<NB, SLOTS>(bl, bt, lr, mdr, mr);
+    modulation<NB, SLOTS>(bl, bt, lt, mdt, mt);
+    if (loud_reached == UINT_MAX) {                  // workgroup-uniform
+      const double n_ref = total_loudness<NB, SLOTS>(bl, bt, er);
+      const double n_test = total_loudness<NB, SLOTS>(bl, bt, et);
+      if (lane == 0) sh.gate[chan] = (n_ref > 0.1 && n_test > 0.1);
+      __syncthreads();
+      const int g = sh.gate[0] | (channels == 2 ? sh.gate[1] : 0);
+      __syncthreads();
+      if (g) loud_reached = blk;
+    }
+    double v0 = 0., w0 = 1.;
+    bool hit = false;
+    if (blk >= 125) {                                // gstpeaq.c:988-993
+      double d1, d2, wt;
+      mod_difference<NB, SLOTS>(bl, bt, 1., mr, mt, mdr[1], d1, d2, wt);
+      d1 *= 100. / sqrt((double)NB);                 // MODE_RMS variant, movs.c:243-244
+      if (lane == MA_RMSMOD) {
+        v0 = d1;
+        w0 = wt;
+        hit = true;
+      }
+    }
+    if (blk >= 125 && blk - 13 >= loud_reached) {    // gstpeaq.c:996-1007
+      // movs.c:551-577 with SWAP_MOD_PATTS_FOR_NOISE_LOUDNESS_MOVS 1
+      const double nl = noise_loudness<NB, SLOTS>(bl, bt, 2.5, 0.3, 1., 0.1, mr, mt, ad_ref, ad_test);
+      const double mc = noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 1., 0., mt, mr, ad_test, ad_ref);
+      // movs.c:679-706 (same switch): reference modulation twice, unadapted FB excitation
+      const double ld = noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 1., 0., mr, mr, ad_ref, er);
+      if (lane == MA_NLASYM) {
+        v0 = nl;
+        w0 = mc;
+        hit = true;
+      }
+      if (lane == MA_LINDIST) {
+        v0 = ld;
+        w0 = 1.;
+        hit = true;
+      }
+    }
+    if (hit) acc.add(v0, w0);
+  }
+
+  if (lane < kBandStride) {
+#pragma unroll
+    for (int v = 0; v < 6; ++v) cs->vec[kLaFiltRef + v][lane] = la[v][0];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      cs->vec[kModPrevRef + v][lane] = mdr[v][0];
+      cs->vec[kModPrevTest + v][lane] = mdt[v][0];
+    }
+  }
+  if (owns) {
+    acc.store(cs->acc[lane]);
+    if (chan == 0) ps->status[lane] = acc.status;
+  }
+  if (chan == 0 && lane == 0) {
+    ps->fb_counter = b_end;
+    ps->loudness_reached = loud_reached;
+  }
+}
+
+hipError_t launch_fb_backend(const FbBackendArgs& a, unsigned n_pairs, hipStream_t stream) {
+  if (n_pairs == 0) return hipSuccess;
+  hipLaunchKernelGGL(fb_backend_kernel, dim3(n_pairs), dim3(64 * a.channels), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // state initialisation (gstpeaq.c:357-361, movaccum.c:276-299, *_state_alloc: zeros)
 // ---------------------------------------------------------------------------
 __global__ void state_init_kernel(PairState* st, unsigned n_pairs) {

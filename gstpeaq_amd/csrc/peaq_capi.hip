@@ -185,6 +185,7 @@ extern "C" int peaq_ctx_device(const peaq_ctx* c) { return c ? c->device : -1; }
 // batch
 // ---------------------------------------------------------------------------
 static const size_t kRecordBudget = (size_t)1536 << 20;   // HBM for per-frame records of one chunk
+static const unsigned kFbBlocksPerChunk = 320;             // filter-bank blocks per launch (multiple of 10)
 
 static unsigned frames_per_chunk(int n_pairs, int channels, uint32_t max_frames) {
   const size_t per_frame = (size_t)n_pairs * channels * kRecDoubles * sizeof(double);
@@ -202,7 +203,7 @@ extern "C" size_t peaq_batch_workspace_bytes(int advanced, int channels, int n_p
   size_t b = (size_t)n_pairs * fc * channels * kRecDoubles * sizeof(double) + (size_t)n_pairs * sizeof(PairState) +
              (size_t)n_pairs * 4 * sizeof(uint32_t);
   if (advanced) {
-    const unsigned bc = fc * 6;
+    const unsigned bc = kFbBlocksPerChunk;
     b += (size_t)n_pairs * bc * channels * kFbRecDoubles * sizeof(double);
     b += (size_t)n_pairs * channels * 2 * (sizeof(FbSignalState) + ((size_t)bc * kFbFrame + kFbRing) * sizeof(double));
   }
@@ -219,7 +220,6 @@ extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double le
   if (!d_ref || !d_test || !d_results) return fail(PEAQ_ERR_ARG, "peaq_batch_run: NULL buffer");
   if ((n_ref == nullptr) != (n_test == nullptr))
     return fail(PEAQ_ERR_ARG, "peaq_batch_run: give both n_ref and n_test or neither");
-  if (advanced) return fail(PEAQ_ERR_STATE, "peaq_batch_run: advanced mode not wired up yet");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   std::lock_guard<std::mutex> lock(c->mu);
   HIP_TRY(hipSetDevice(c->device));
@@ -231,19 +231,22 @@ extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double le
   c->events_used = 0;
 
   // ---- frame counts -------------------------------------------------------------------
-  uint32_t max_frames = 0;
+  uint32_t max_frames = 0, max_blocks = 0;
   const uint32_t* d_nref = nullptr;
   const uint32_t* d_ntest = nullptr;
   const uint32_t* d_nframes = nullptr;
+  const uint32_t* d_nblocks = nullptr;
   if (n_ref) {
-    std::vector<uint32_t> h(3 * (size_t)n_pairs);
+    std::vector<uint32_t> h(4 * (size_t)n_pairs);
     for (int p = 0; p < n_pairs; ++p) {
       if (n_ref[p] > pair_stride || n_test[p] > pair_stride)
         return fail(PEAQ_ERR_ARG, "peaq_batch_run: a pair is longer than pair_stride");
       h[p] = n_ref[p];
       h[n_pairs + p] = n_test[p];
       h[2 * (size_t)n_pairs + p] = count_frames(n_ref[p], n_test[p], kFrame, kHop);
+      h[3 * (size_t)n_pairs + p] = count_frames(n_ref[p], n_test[p], kFbFrame, kFbFrame);
       max_frames = std::max(max_frames, h[2 * (size_t)n_pairs + p]);
+      max_blocks = std::max(max_blocks, h[3 * (size_t)n_pairs + p]);
     }
     HIP_TRY(c->counts.reserve(h.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpyAsync(c->counts.p, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
@@ -251,9 +254,11 @@ extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double le
     d_nref = c->counts.as<uint32_t>();
     d_ntest = d_nref + n_pairs;
     d_nframes = d_nref + 2 * (size_t)n_pairs;
+    d_nblocks = d_nref + 3 * (size_t)n_pairs;
   } else {
     if (n_uniform > pair_stride) return fail(PEAQ_ERR_ARG, "peaq_batch_run: n_uniform > pair_stride");
     max_frames = count_frames(n_uniform, n_uniform, kFrame, kHop);
+    max_blocks = count_frames(n_uniform, n_uniform, kFbFrame, kFbFrame);
   }
 
   const unsigned fc = frames_per_chunk(n_pairs, channels, max_frames);
@@ -279,15 +284,15 @@ extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double le
   fa.channels = channels;
   fa.level_factor = fft_level_factor(level_db);
   fa.common = c->d_common;
-  fa.bands = c->d_bands109;
+  fa.bands = advanced ? c->d_bands55 : c->d_bands109;    // gstpeaq.c:521-526
   fa.records = c->records.as<double>();
   BackendArgs ba{};
   ba.records = fa.records;
   ba.n_frames = d_nframes;
   ba.n_frames_uniform = max_frames;
   ba.channels = channels;
-  ba.advanced = 0;
-  ba.bands = c->d_bands109;
+  ba.advanced = advanced ? 1 : 0;
+  ba.bands = fa.bands;
   ba.state = c->state.as<PairState>();
 
   for (uint32_t f0 = 0; f0 < max_frames; f0 += fc) {
@@ -299,12 +304,65 @@ extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double le
     hipEvent_t e0 = c->next_event(), e1 = c->next_event(), e2 = c->next_event();
     if (!e0 || !e1 || !e2) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(e0, stream));
-    HIP_TRY(launch_frontend(109, fa, n_pairs, stream));
+    HIP_TRY(launch_frontend(advanced ? 55 : 109, fa, n_pairs, stream));
     HIP_TRY(hipEventRecord(e1, stream));
     HIP_TRY(launch_backend(ba, n_pairs, stream));
     HIP_TRY(hipEventRecord(e2, stream));
     c->spans.push_back({e0, e1, 0});
     c->spans.push_back({e1, e2, 1});
+  }
+  if (advanced && max_blocks > 0) {
+    // ---- filter-bank path: blocks of 192 samples (gstpeaq.c:648-652) ------------------
+    const unsigned n_signals = (unsigned)n_pairs * channels * 2;
+    const unsigned bc = std::min<unsigned>(kFbBlocksPerChunk, (max_blocks + 9) / 10 * 10);
+    const size_t row_stride = (size_t)kFbRing + (size_t)bc * kFbFrame;
+    HIP_TRY(c->hp_scratch.reserve((size_t)n_signals * row_stride * sizeof(double)));
+    HIP_TRY(c->fb_records.reserve((size_t)n_pairs * bc * channels * kFbRecDoubles * sizeof(double)));
+    HIP_TRY(c->fbstate.reserve((size_t)n_signals * sizeof(FbSignalState)));
+    HIP_TRY(hipMemsetAsync(c->fbstate.p, 0, (size_t)n_signals * sizeof(FbSignalState), stream));
+    FbFrontArgs ff{};
+    ff.ref = d_ref;
+    ff.test = d_test;
+    ff.pair_stride = pair_stride;
+    ff.n_ref = d_nref;
+    ff.n_test = d_ntest;
+    ff.n_uniform_ref = ff.n_uniform_test = n_uniform;
+    ff.n_blocks = d_nblocks;
+    ff.n_blocks_uniform = max_blocks;
+    ff.block_origin = 0;
+    ff.channels = channels;
+    ff.level_factor = fb_level_factor(level_db);
+    ff.bands = c->d_bands40;
+    ff.fb = c->d_fb;
+    ff.fbstate = c->fbstate.as<FbSignalState>();
+    ff.hp_scratch = c->hp_scratch.as<double>();
+    ff.hp_row_stride = row_stride;
+    ff.records = c->fb_records.as<double>();
+    FbBackendArgs fbk{};
+    fbk.records = ff.records;
+    fbk.n_blocks = d_nblocks;
+    fbk.n_blocks_uniform = max_blocks;
+    fbk.channels = channels;
+    fbk.bands = c->d_bands40;
+    fbk.state = c->state.as<PairState>();
+    unsigned prev = 0;
+    for (uint32_t b0 = 0; b0 < max_blocks; b0 += bc) {
+      const unsigned nb = std::min<uint32_t>(bc, max_blocks - b0);
+      ff.block0 = b0;
+      ff.blocks_per_launch = nb;
+      ff.prev_blocks = prev;
+      ff.first_launch = b0 == 0;
+      fbk.block0 = b0;
+      fbk.blocks_per_launch = nb;
+      hipEvent_t e0 = c->next_event(), e1 = c->next_event();
+      if (!e0 || !e1) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
+      HIP_TRY(hipEventRecord(e0, stream));
+      HIP_TRY(launch_fb_frontend(ff, n_pairs, stream));
+      HIP_TRY(launch_fb_backend(fbk, n_pairs, stream));
+      HIP_TRY(hipEventRecord(e1, stream));
+      c->spans.push_back({e0, e1, 2});
+      prev = nb;
+    }
   }
   HIP_TRY(launch_finalize(c->state.as<PairState>(), advanced, channels, n_pairs,
                           reinterpret_cast<ResultRecord*>(d_results), stream));
@@ -403,6 +461,7 @@ extern "C" int peaq_debug_frontend(peaq_ctx* c, int bands, int channels, double 
 namespace {
 
 constexpr unsigned kSessionMaxFrames = 64;   // FFT frames per launch of a session
+constexpr unsigned kSessionMaxBlocks = 120;  // filter-bank blocks per launch of a session
 
 // host-side stand-in for a GstAdapter: the not yet consumed tail of one pad's stream
 struct PadFifo {
@@ -420,7 +479,12 @@ struct peaq_session {
   std::mutex mu;
   PadFifo pad[2];
   uint64_t fft_pos[2] = {0, 0};   // stream sample where the next FFT frame starts, per pad
+  uint64_t fb_pos[2] = {0, 0};    // ... where the next filter-bank block starts (advanced)
   uint32_t frames_done = 0;
+  uint32_t blocks_done = 0;
+  uint32_t fb_prev_blocks = 0;
+  bool fb_first = true;
+  DevBuf fb_records, fbstate, hp_rows;
   hipStream_t stream = nullptr;
   hipEvent_t staged = nullptr;    // the pinned staging buffers may be rewritten after this
   bool staged_pending = false;
@@ -430,7 +494,7 @@ struct peaq_session {
 };
 
 static int session_alloc(peaq_session* s) {
-  s->stage_samples = (size_t)(kSessionMaxFrames - 1) * kHop + kFrame;
+  s->stage_samples = (size_t)(kSessionMaxFrames - 1) * kHop + kFrame;   // >= kSessionMaxBlocks * 192
   const size_t bytes = s->stage_samples * s->channels * sizeof(float);
   for (int p = 0; p < 2; ++p) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_stage[p]), bytes, hipHostMallocDefault));
@@ -442,6 +506,13 @@ static int session_alloc(peaq_session* s) {
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&s->staged, hipEventDisableTiming));
   HIP_TRY(launch_state_init(s->state.as<PairState>(), s->advanced, 1, s->stream));
+  if (s->advanced) {
+    const unsigned n_signals = 2 * s->channels;
+    HIP_TRY(s->fb_records.reserve((size_t)kSessionMaxBlocks * s->channels * kFbRecDoubles * sizeof(double)));
+    HIP_TRY(s->fbstate.reserve(n_signals * sizeof(FbSignalState)));
+    HIP_TRY(hipMemsetAsync(s->fbstate.p, 0, n_signals * sizeof(FbSignalState), s->stream));
+    HIP_TRY(s->hp_rows.reserve((size_t)n_signals * (kFbRing + (size_t)kSessionMaxBlocks * kFbFrame) * sizeof(double)));
+  }
   return PEAQ_OK;
 }
 
@@ -451,7 +522,6 @@ extern "C" int peaq_session_create(peaq_ctx* c, int advanced, int channels, doub
   if (channels != 1 && channels != 2) return fail(PEAQ_ERR_ARG, "peaq_session_create: channels must be 1 or 2");
   if (!(level_db >= 0. && level_db <= 130.))
     return fail(PEAQ_ERR_ARG, "peaq_session_create: playback level outside 0..130 dB (gstpeaq.c:275-281)");
-  if (advanced) return fail(PEAQ_ERR_STATE, "peaq_session_create: advanced mode not wired up yet");
   HIP_TRY(hipSetDevice(c->device));
   peaq_session* s = new (std::nothrow) peaq_session;
   if (!s) return fail(PEAQ_ERR_NOMEM, "out of host memory");
@@ -479,6 +549,9 @@ extern "C" void peaq_session_destroy(peaq_session* s) {
   s->records.release();
   s->state.release();
   s->result.release();
+  s->fb_records.release();
+  s->fbstate.release();
+  s->hp_rows.release();
   if (s->staged) (void)hipEventDestroy(s->staged);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -487,15 +560,14 @@ extern "C" void peaq_session_destroy(peaq_session* s) {
 // run `nf` FFT frames whose first sample is fft_pos[] on each pad; the two
 // signals contribute n_valid[] samples (shorter than a whole frame only for
 // the flush frame).
-static int session_run_frames(peaq_session* s, unsigned nf, const uint64_t n_valid[2]) {
-  peaq_ctx* c = s->ctx;
+static int session_stage(peaq_session* s, const uint64_t pos[2], const uint64_t n_valid[2]) {
   if (s->staged_pending) {
     HIP_TRY(hipEventSynchronize(s->staged));
     s->staged_pending = false;
   }
   for (int p = 0; p < 2; ++p) {
     const PadFifo& f = s->pad[p];
-    const size_t off = (size_t)(s->fft_pos[p] - f.base) * s->channels;
+    const size_t off = (size_t)(pos[p] - f.base) * s->channels;
     const size_t cnt = (size_t)n_valid[p] * s->channels;
     if (cnt) {
       std::memcpy(s->h_stage[p], f.buf.data() + off, cnt * sizeof(float));
@@ -504,6 +576,15 @@ static int session_run_frames(peaq_session* s, unsigned nf, const uint64_t n_val
   }
   HIP_TRY(hipEventRecord(s->staged, s->stream));
   s->staged_pending = true;
+  return PEAQ_OK;
+}
+
+static int session_run_frames(peaq_session* s, unsigned nf, const uint64_t n_valid[2]) {
+  peaq_ctx* c = s->ctx;
+  {
+    const int rc = session_stage(s, s->fft_pos, n_valid);
+    if (rc != PEAQ_OK) return rc;
+  }
   FrontendArgs fa{};
   fa.ref = s->d_sig[0].as<float>();
   fa.test = s->d_sig[1].as<float>();
@@ -517,27 +598,70 @@ static int session_run_frames(peaq_session* s, unsigned nf, const uint64_t n_val
   fa.frames_per_launch = nf;
   fa.level_factor = fft_level_factor(s->level_db);
   fa.common = c->d_common;
-  fa.bands = c->d_bands109;
+  fa.bands = s->advanced ? c->d_bands55 : c->d_bands109;
   fa.records = s->records.as<double>();
-  HIP_TRY(launch_frontend(109, fa, 1, s->stream));
+  HIP_TRY(launch_frontend(s->advanced ? 55 : 109, fa, 1, s->stream));
   BackendArgs ba{};
   ba.records = fa.records;
   ba.frame0 = s->frames_done;
   ba.frames_per_launch = nf;
   ba.n_frames_uniform = s->frames_done + nf;
   ba.channels = s->channels;
-  ba.advanced = 0;
-  ba.bands = c->d_bands109;
+  ba.advanced = s->advanced;
+  ba.bands = fa.bands;
   ba.state = s->state.as<PairState>();
   HIP_TRY(launch_backend(ba, 1, s->stream));
   s->frames_done += nf;
   return PEAQ_OK;
 }
 
+// run `nb` filter-bank blocks starting at fb_pos[] (advanced mode)
+static int session_run_blocks(peaq_session* s, unsigned nb, const uint64_t n_valid[2]) {
+  peaq_ctx* c = s->ctx;
+  {
+    const int rc = session_stage(s, s->fb_pos, n_valid);
+    if (rc != PEAQ_OK) return rc;
+  }
+  FbFrontArgs ff{};
+  ff.ref = s->d_sig[0].as<float>();
+  ff.test = s->d_sig[1].as<float>();
+  ff.pair_stride = s->stage_samples;
+  ff.n_uniform_ref = static_cast<uint32_t>(n_valid[0]);
+  ff.n_uniform_test = static_cast<uint32_t>(n_valid[1]);
+  ff.n_blocks_uniform = s->blocks_done + nb;
+  ff.block_origin = s->blocks_done;
+  ff.channels = s->channels;
+  ff.block0 = s->blocks_done;
+  ff.blocks_per_launch = nb;
+  ff.prev_blocks = s->fb_prev_blocks;
+  ff.first_launch = s->fb_first;
+  ff.level_factor = fb_level_factor(s->level_db);
+  ff.bands = c->d_bands40;
+  ff.fb = c->d_fb;
+  ff.fbstate = s->fbstate.as<FbSignalState>();
+  ff.hp_scratch = s->hp_rows.as<double>();
+  ff.hp_row_stride = kFbRing + (size_t)kSessionMaxBlocks * kFbFrame;
+  ff.records = s->fb_records.as<double>();
+  HIP_TRY(launch_fb_frontend(ff, 1, s->stream));
+  FbBackendArgs fbk{};
+  fbk.records = ff.records;
+  fbk.block0 = s->blocks_done;
+  fbk.blocks_per_launch = nb;
+  fbk.n_blocks_uniform = s->blocks_done + nb;
+  fbk.channels = s->channels;
+  fbk.bands = c->d_bands40;
+  fbk.state = s->state.as<PairState>();
+  HIP_TRY(launch_fb_backend(fbk, 1, s->stream));
+  s->blocks_done += nb;
+  s->fb_prev_blocks = nb;
+  s->fb_first = false;
+  return PEAQ_OK;
+}
+
 static void session_trim(peaq_session* s) {
   for (int p = 0; p < 2; ++p) {
     PadFifo& f = s->pad[p];
-    const uint64_t keep_from = s->fft_pos[p];
+    const uint64_t keep_from = s->advanced ? std::min(s->fft_pos[p], s->fb_pos[p]) : s->fft_pos[p];
     if (keep_from > f.base) {
       const size_t drop = (size_t)(keep_from - f.base) * s->channels;
       f.buf.erase(f.buf.begin(), f.buf.begin() + std::min(drop, f.buf.size()));
@@ -559,6 +683,18 @@ static int session_drain(peaq_session* s) {
     if (rc != PEAQ_OK) return rc;
     s->fft_pos[0] += (uint64_t)nf * kHop;
     s->fft_pos[1] += (uint64_t)nf * kHop;
+  }
+  if (s->advanced) {
+    for (;;) {
+      const uint64_t av = std::min(s->pad[0].total - s->fb_pos[0], s->pad[1].total - s->fb_pos[1]);
+      if (av < (uint64_t)kFbFrame) break;
+      const unsigned nb = static_cast<unsigned>(std::min<uint64_t>(av / kFbFrame, kSessionMaxBlocks));
+      const uint64_t nv[2] = {(uint64_t)nb * kFbFrame, (uint64_t)nb * kFbFrame};
+      const int rc = session_run_blocks(s, nb, nv);
+      if (rc != PEAQ_OK) return rc;
+      s->fb_pos[0] += nv[0];
+      s->fb_pos[1] += nv[1];
+    }
   }
   session_trim(s);
   return PEAQ_OK;
@@ -593,8 +729,18 @@ extern "C" int peaq_session_flush(peaq_session* s) {
     if (rc != PEAQ_OK) return rc;
     s->fft_pos[0] += nv[0];
     s->fft_pos[1] += nv[1];
-    session_trim(s);
   }
+  if (s->advanced) {                                 // gstpeaq.c:769-771
+    const uint64_t lr = s->pad[0].total - s->fb_pos[0], lt = s->pad[1].total - s->fb_pos[1];
+    if (lr || lt) {
+      const uint64_t nv[2] = {std::min<uint64_t>(lr, kFbFrame), std::min<uint64_t>(lt, kFbFrame)};
+      const int rc = session_run_blocks(s, 1, nv);
+      if (rc != PEAQ_OK) return rc;
+      s->fb_pos[0] += nv[0];
+      s->fb_pos[1] += nv[1];
+    }
+  }
+  session_trim(s);
   return PEAQ_OK;
 }
 
@@ -617,8 +763,14 @@ extern "C" int peaq_session_reset(peaq_session* s) {
   for (int p = 0; p < 2; ++p) {
     s->pad[p] = PadFifo();
     s->fft_pos[p] = 0;
+    s->fb_pos[p] = 0;
   }
   s->frames_done = 0;
+  s->blocks_done = 0;
+  s->fb_prev_blocks = 0;
+  s->fb_first = true;
+  if (s->advanced)
+    HIP_TRY(hipMemsetAsync(s->fbstate.p, 0, 2 * s->channels * sizeof(FbSignalState), s->stream));
   HIP_TRY(launch_state_init(s->state.as<PairState>(), s->advanced, 1, s->stream));
   return PEAQ_OK;
 }

@@ -59,19 +59,24 @@ struct FbFrontArgs {
   const float* ref;
   const float* test;
   size_t pair_stride;
-  const uint32_t* n_ref;
+  const uint32_t* n_ref;        // per-pair lengths (device) or nullptr
   const uint32_t* n_test;
-  uint32_t n_uniform;
-  const uint32_t* n_blocks;
+  uint32_t n_uniform_ref, n_uniform_test;
+  const uint32_t* n_blocks;     // per-pair total block count (device) or nullptr
   uint32_t n_blocks_uniform;
-  long long sample_base;
+  // block b starts at buffer sample (b - block_origin) * 192 + off_{ref,test}
+  unsigned block_origin;
+  long long off_ref, off_test;
   int channels;
   unsigned block0, blocks_per_launch;
+  unsigned prev_blocks;         // blocks_per_launch of the previous launch on these rows
+  int first_launch;             // no history yet: the filter-bank delay line starts at zero
   double level_factor;          // fbearmodel.c:252-253
   const BandTables* bands;      // 40 bands
   const FbTables* fb;
   FbSignalState* fbstate;       // [pair][channel][2]
-  double* hp_scratch;           // [pair][channel][2][blocks_per_launch*192 + 1456]
+  double* hp_scratch;           // rows [signal][hp_row_stride]: 1456 history + filtered samples of the launch
+  size_t hp_row_stride;
   double* records;              // [pair][block - block0][channel][kFbRecDoubles]
 };
 hipError_t launch_fb_frontend(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream);

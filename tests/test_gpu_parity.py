@@ -102,6 +102,23 @@ def test_batch_basic_matches_reference_goldens(gpu, channels):
     print(f"max |dODG| vs reference over {len(recs)} cases: {worst:.3e}")
 
 
+@pytest.mark.parametrize("channels", [1, 2])
+def test_batch_advanced_matches_reference_goldens(gpu, channels):
+    """advanced version (55-band FFT model + 40-band filter bank, 5 MOVs) against the outputs
+    of the real reference element; pinned by nothing else in the reference but its
+    conformance table"""
+    recs = [r for r in gpu.e2e_records(1) if r["case"]["channels"] == channels]
+    inputs = [case_defs.make_inputs(r["case"]) for r in recs]
+    got = gpu.run_batch(inputs, 1, channels)
+    worst = 0.0
+    for g, rec in zip(got, recs):
+        assert g["fb_blocks"] == rec["fb_frames"], rec["case"]["name"]
+        gpu.compare_result(g, rec, rtol=1e-7, atol=1e-9, odg_atol=1e-6)
+        if not np.isnan(float(rec["odg"])):
+            worst = max(worst, abs(g["odg"] - float(rec["odg"])))
+    print(f"max |dODG| vs reference over {len(recs)} advanced cases: {worst:.3e}")
+
+
 def test_reference_odg_regression_strings_on_gpu(gpu):
     # runtest-1.0.sh:18,28
     a = case_defs.make_inputs(dict(kind="ats", wave_ref="sine", wave_test="sine", n=131072, channels=1))
@@ -127,13 +144,14 @@ def test_batch_matches_oracle_on_seeded_pairs(gpu):
     print(f"max |dODG| vs oracle: {worst:.3e}")
 
 
-def test_session_streaming_equals_batch(gpu):
+@pytest.mark.parametrize("advanced", [0, 1])
+def test_session_streaming_equals_batch(gpu, advanced):
     """pad_chain delivers arbitrary buffer sizes on either pad (gstpeaq.c:614-661)"""
     import gstpeaq_amd
     case = dict(kind="synth", seed=3, channels=2, n=150000, test_trim=1234)
     ref, test = case_defs.make_inputs(case)
-    whole = gpu.run_batch([(ref, test)], 0, 2)[0]
-    s = gstpeaq_amd.Session(gpu.ctx(), 0, 2)
+    whole = gpu.run_batch([(ref, test)], advanced, 2)[0]
+    s = gstpeaq_amd.Session(gpu.ctx(), advanced, 2)
     rng = np.random.default_rng(1)
     pr = pt = 0
     mid = None
@@ -151,7 +169,10 @@ def test_session_streaming_equals_batch(gpu):
     s.flush()
     got = s.results()
     assert mid["frames"] > 0 and mid["frames"] < got["frames"]
-    assert got["frames"] == whole["frames"]
-    assert np.array_equal(got["movs"], whole["movs"]) and got["odg"] == whole["odg"]
+    assert got["frames"] == whole["frames"] and got["fb_blocks"] == whole["fb_blocks"]
+    # same kernels, same per-frame arithmetic; the filter bank walks the stream in different
+    # tile alignments, which only moves FP64 rounding
+    np.testing.assert_allclose(got["movs"], whole["movs"], rtol=1e-10 if advanced else 0, atol=0)
+    assert abs(got["odg"] - whole["odg"]) <= (1e-10 if advanced else 0)
     assert s.results()["odg"] == got["odg"]            # idempotent
     s.close()
