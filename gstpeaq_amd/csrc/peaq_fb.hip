@@ -37,7 +37,7 @@ constexpr int coef_offset(int b) {
 }
 
 constexpr double kSlopeA = 0.993355506255034;      // fbearmodel.c:49
-constexpr double kLnDist = -0.08137163435861389;   // ln(0.921851456499719), fbearmodel.c:50
+constexpr double kLnDist = -0.08137117849224008;   // ln(0.921851456499719), DIST of fbearmodel.c:50
 constexpr double kCL = 0.0802581846102741;         // fbearmodel.c:51
 
 // ---------------------------------------------------------------------------
