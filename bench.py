@@ -124,19 +124,12 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
-    # the one collective of the path: gather the per-pair ODG scalars
-    odg = results[:, 12].contiguous()
-    frames = results[:, 14]
-    frame_pairs_rank = float(frames.sum().item())
-    if dist:
-        all_odg = [torch.empty_like(odg) for _ in range(world)]
-        dist.all_gather(all_odg, odg)
-        odg = torch.cat(all_odg)
-        fp = torch.tensor([frame_pairs_rank], dtype=torch.float64, device=dev)
-        dist.all_reduce(fp)
-        frame_pairs_all = float(fp.item())
-    else:
-        frame_pairs_all = frame_pairs_rank
+    # the one collective of the path: gather the per-pair result records
+    from gstpeaq_amd import parallel
+    frame_pairs_rank = float(results[:, 14].sum().item())
+    gathered = parallel.gather_results(results, world, dist)
+    odg = gathered[:, 12]
+    frame_pairs_all = float(gathered[:, 14].sum().item())
 
     if rank == 0:
         value = frame_pairs_all * args.steps / elapsed
@@ -170,7 +163,7 @@ def main():
                        "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "frontend_kernel<109>", "launches": timing["frontend_launches"],
+                         "kernel": "frontend_kernel<55>" if args.advanced else "frontend_kernel<109>", "launches": timing["frontend_launches"],
                          "avg_launch_ms": timing["frontend_ms"] / max(timing["frontend_launches"], 1),
                          "algorithmic_bytes_per_launch": frame_pairs_rank * ALGO_BYTES_PER_FRAME_PAIR
                                                          / max(timing["frontend_launches"], 1),

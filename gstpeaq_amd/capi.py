@@ -60,6 +60,8 @@ def load_library():
     vp, dp, fp, u32p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
     L.peaq_last_error.restype = C.c_char_p
     L.peaq_version.restype = C.c_char_p
+    L.peaq_frame_count.restype = C.c_uint32
+    L.peaq_frame_count.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
     L.peaq_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.peaq_ctx_destroy.argtypes = [vp]
     L.peaq_ctx_device.argtypes = [vp]

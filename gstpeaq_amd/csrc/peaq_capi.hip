@@ -61,6 +61,10 @@ static uint32_t count_frames(uint64_t n_ref, uint64_t n_test, uint32_t frame, ui
   return static_cast<uint32_t>(full + (left ? 1 : 0));
 }
 
+extern "C" uint32_t peaq_frame_count(uint64_t n_ref, uint64_t n_test, int filter_bank) {
+  return filter_bank ? count_frames(n_ref, n_test, kFbFrame, kFbFrame) : count_frames(n_ref, n_test, kFrame, kHop);
+}
+
 // ---------------------------------------------------------------------------
 // growable device buffer
 // ---------------------------------------------------------------------------

@@ -51,6 +51,12 @@ typedef struct {
 } peaq_result;
 
 const char *peaq_last_error (void);
+/* Number of frames the element processes for signals of n_ref / n_test samples per
+ * channel: full frames while both adapters hold one (do_processing,
+ * gstpeaq.c:596-611) plus ONE zero-padded frame if anything is left on either
+ * side (do_flush, :716-745).  filter_bank = 0: FFT frames (2048 / hop 1024);
+ * 1: filter-bank blocks (192 / 192).  Pure host arithmetic, no GPU needed. */
+uint32_t peaq_frame_count (uint64_t n_ref, uint64_t n_test, int filter_bank);
 /* "x.y.z gfx950" */
 const char *peaq_version (void);
 
