@@ -1,0 +1,219 @@
+/* peaq.c -- the `peaq REFFILE TESTFILE` command-line tool on the MI355X engine.
+ *
+ * Same interface as the reference's CLI (src/peaq.c): options --basic (default),
+ * --advanced, --version; prints
+ *     Objective Difference Grade: %.3f
+ *     Distortion Index: %.3f
+ * (peaq.c:217-220); exit status 0, 1 on usage errors (:110-133), 2 when the
+ * engine cannot be set up (:147-195).  The reference builds a GStreamer pipeline
+ * filesrc ! wavparse ! audioconvert ! audioresample ! peaq (:154-209); this tool
+ * reads RIFF/WAVE itself (PCM 8/16/24/32 bit and IEEE float 32/64, mono or
+ * stereo) and feeds the engine's session API directly, so that it works on a
+ * box without gst-plugins-good.  Integer PCM is scaled by 1/2^(bits-1) like
+ * audioconvert does (S16 -> x/32768, verified in SURVEY.md 8(c)).  Files must be
+ * 48 kHz (the ear models are defined for 48 kHz only, earmodel.c:43); there is
+ * no resampler here.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "peaq_amd.h"
+
+typedef struct
+{
+  float *samples;               /* interleaved */
+  size_t frames;                /* samples per channel */
+  int channels, rate;
+} wav_t;
+
+static uint32_t
+rd32 (const unsigned char *p)
+{
+  return (uint32_t) p[0] | ((uint32_t) p[1] << 8) | ((uint32_t) p[2] << 16) | ((uint32_t) p[3] << 24);
+}
+
+static int
+wav_read (const char *path, wav_t * w)
+{
+  FILE *f = fopen (path, "rb");
+  unsigned char hdr[12], ck[8];
+  int fmt_tag = 0, bits = 0, have_fmt = 0, block_align = 0;
+  memset (w, 0, sizeof *w);
+  if (!f) {
+    fprintf (stderr, "Error: cannot open %s\n", path);
+    return -1;
+  }
+  if (fread (hdr, 1, 12, f) != 12 || memcmp (hdr, "RIFF", 4) || memcmp (hdr + 8, "WAVE", 4)) {
+    fprintf (stderr, "Error: %s is not a RIFF/WAVE file\n", path);
+    fclose (f);
+    return -1;
+  }
+  while (fread (ck, 1, 8, f) == 8) {
+    uint32_t size = rd32 (ck + 4);
+    if (!memcmp (ck, "fmt ", 4)) {
+      unsigned char fmt[40];
+      uint32_t n = size < sizeof fmt ? size : sizeof fmt;
+      if (size < 16 || fread (fmt, 1, n, f) != n)
+        break;
+      fmt_tag = fmt[0] | (fmt[1] << 8);
+      w->channels = fmt[2] | (fmt[3] << 8);
+      w->rate = (int) rd32 (fmt + 4);
+      block_align = fmt[12] | (fmt[13] << 8);
+      bits = fmt[14] | (fmt[15] << 8);
+      if (fmt_tag == 0xFFFE && size >= 26)      /* WAVE_FORMAT_EXTENSIBLE: sub-format GUID */
+        fmt_tag = fmt[24] | (fmt[25] << 8);
+      have_fmt = 1;
+      if (size > n)
+        fseek (f, (long) (size - n), SEEK_CUR);
+      if (size & 1)
+        fseek (f, 1, SEEK_CUR);
+    } else if (!memcmp (ck, "data", 4) && have_fmt) {
+      size_t bytes_per = (size_t) bits / 8, total, i;
+      unsigned char *raw;
+      if (w->channels < 1 || w->channels > 2 || block_align != (int) bytes_per * w->channels ||
+          !((fmt_tag == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32)) ||
+              (fmt_tag == 3 && (bits == 32 || bits == 64)))) {
+        fprintf (stderr, "Error: %s: unsupported WAVE format (tag %d, %d bit, %d channels)\n", path,
+            fmt_tag, bits, w->channels);
+        fclose (f);
+        return -1;
+      }
+      raw = malloc (size ? size : 1);
+      total = fread (raw, 1, size, f) / bytes_per;     /* tolerate a truncated data chunk */
+      total -= total % w->channels;
+      w->frames = total / w->channels;
+      w->samples = malloc ((total ? total : 1) * sizeof (float));
+      for (i = 0; i < total; i++) {
+        const unsigned char *p = raw + i * bytes_per;
+        double v;
+        if (fmt_tag == 3) {
+          if (bits == 32) {
+            float t;
+            memcpy (&t, p, 4);
+            v = t;
+          } else {
+            memcpy (&v, p, 8);
+          }
+        } else if (bits == 8) {
+          v = ((int) p[0] - 128) / 128.;
+        } else if (bits == 16) {
+          v = (int16_t) (p[0] | (p[1] << 8)) / 32768.;
+        } else if (bits == 24) {
+          int32_t t = (int32_t) ((uint32_t) p[0] << 8 | (uint32_t) p[1] << 16 | (uint32_t) p[2] << 24) >> 8;
+          v = t / 8388608.;
+        } else {
+          v = (int32_t) rd32 (p) / 2147483648.;
+        }
+        w->samples[i] = (float) v;
+      }
+      free (raw);
+      fclose (f);
+      return 0;
+    } else {
+      fseek (f, (long) (size + (size & 1)), SEEK_CUR);
+    }
+  }
+  fprintf (stderr, "Error: %s: no usable fmt/data chunks\n", path);
+  fclose (f);
+  return -1;
+}
+
+static void
+usage (const char *prog)
+{
+  printf ("Usage:\n  %s [OPTION...] REFFILE TESTFILE\n\n"
+      "peaq computes the Objective Difference Grade based on ITU-R BS.1387-1 (but it\n"
+      "does not meet its conformance requirements), on an AMD MI355X.\n\n"
+      "  --version     print version information\n"
+      "  --advanced    use advanced version\n"
+      "  --basic       use basic version (default)\n"
+      "  --level=DB    playback level in dB SPL of a full-scale sine (default 92)\n", prog);
+}
+
+int
+main (int argc, char **argv)
+{
+  int advanced = 0, i, nfiles = 0, rc;
+  double level = 92.;
+  const char *files[2] = { NULL, NULL };
+  wav_t ref, test;
+  peaq_ctx *ctx = NULL;
+  peaq_session *s = NULL;
+  peaq_result r;
+  size_t pos;
+
+  for (i = 1; i < argc; i++) {
+    if (!strcmp (argv[i], "--advanced"))
+      advanced = 1;
+    else if (!strcmp (argv[i], "--basic"))
+      advanced = 0;
+    else if (!strncmp (argv[i], "--level=", 8))
+      level = atof (argv[i] + 8);
+    else if (!strcmp (argv[i], "--version")) {
+      printf ("peaq (gstpeaq_amd) %s\n", peaq_version ());
+      return 0;
+    } else if (!strcmp (argv[i], "--help") || !strcmp (argv[i], "-h")) {
+      usage (argv[0]);
+      return 0;
+    } else if (argv[i][0] == '-' && argv[i][1] == '-') {
+      fprintf (stderr, "Failed to initialize: Unknown option %s\n", argv[i]);
+      return 1;
+    } else if (nfiles < 2)
+      files[nfiles++] = argv[i];
+    else
+      nfiles++;
+  }
+  if (nfiles != 2) {
+    usage (argv[0]);
+    return 1;
+  }
+  if (wav_read (files[0], &ref) || wav_read (files[1], &test))
+    return 2;
+  if (ref.rate != 48000 || test.rate != 48000) {
+    fprintf (stderr, "Error: both files must be sampled at 48 kHz (got %d and %d Hz)\n", ref.rate, test.rate);
+    return 2;
+  }
+  if (ref.channels != test.channels) {
+    /* the element negotiates equal channel counts via audioconvert; up-mix the mono side */
+    wav_t *m = ref.channels == 1 ? &ref : &test;
+    float *st = malloc ((m->frames ? m->frames : 1) * 2 * sizeof (float));
+    for (pos = 0; pos < m->frames; pos++)
+      st[2 * pos] = st[2 * pos + 1] = m->samples[pos];
+    free (m->samples);
+    m->samples = st;
+    m->channels = 2;
+  }
+  if (peaq_ctx_create (getenv ("PEAQ_AMD_DEVICE") ? atoi (getenv ("PEAQ_AMD_DEVICE")) : 0, &ctx) != PEAQ_OK ||
+      peaq_session_create (ctx, advanced, ref.channels, level, &s) != PEAQ_OK) {
+    printf ("Error: peaq engine could not be instantiated - %s\n", peaq_last_error ());
+    return 2;
+  }
+  /* feed like two streaming threads would: alternating buffers of 4096 samples */
+  for (pos = 0; pos < ref.frames || pos < test.frames; pos += 4096) {
+    rc = PEAQ_OK;
+    if (pos < ref.frames)
+      rc = peaq_session_push (s, 0, ref.samples + pos * ref.channels,
+          ref.frames - pos < 4096 ? ref.frames - pos : 4096);
+    if (rc == PEAQ_OK && pos < test.frames)
+      rc = peaq_session_push (s, 1, test.samples + pos * test.channels,
+          test.frames - pos < 4096 ? test.frames - pos : 4096);
+    if (rc != PEAQ_OK) {
+      printf ("Error: %s\n", peaq_last_error ());
+      return 2;
+    }
+  }
+  if (peaq_session_flush (s) != PEAQ_OK || peaq_session_results (s, &r) != PEAQ_OK) {
+    printf ("Error: %s\n", peaq_last_error ());
+    return 2;
+  }
+  printf ("Objective Difference Grade: %.3f\n", r.odg);
+  printf ("Distortion Index: %.3f\n", r.di);
+  peaq_session_destroy (s);
+  peaq_ctx_destroy (ctx);
+  free (ref.samples);
+  free (test.samples);
+  return 0;
+}

@@ -1,0 +1,403 @@
+/* gstpeaq_amd.c -- the `peaq` GStreamer element on top of libpeaq_amd.so.
+ *
+ * Host side of the drop-in boundary: same element name, pads,
+ * caps, properties, console text and flush semantics as the element of
+ * HSU-ANT/gstpeaq (reference src/gstpeaq.c), but everything below the adapters
+ * -- ear models, pattern processing, MOVs, accumulators, neural network -- is
+ * one peaq_session of the MI355X engine (include/peaq_amd.h).
+ *
+ *   element "peaq", klass Sink/Audio, GST_ELEMENT_FLAG_SINK   gstpeaq.c:319-323,355
+ *   sink pads "ref" and "test", ALWAYS                         gstpeaq.c:154-165
+ *   caps audio/x-raw F32LE interleaved 48000 Hz                gstpeaq.c:146-152
+ *   both pads negotiate the same channel count                 gstpeaq.c:216-244,689-708
+ *   properties playback_level, advanced, console-output,
+ *              di, odg, totalsnr                               gstpeaq.c:273-317
+ *   PAUSED->READY flushes with zero padding and evaluates ODG  gstpeaq.c:764-778
+ */
+#include <gst/gst.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "peaq_amd.h"
+
+#ifndef PACKAGE
+#define PACKAGE "gstpeaq-amd"
+#endif
+#ifndef PACKAGE_VERSION
+#define PACKAGE_VERSION "0.1.0"
+#endif
+
+GST_DEBUG_CATEGORY_STATIC (peaq_amd_debug);
+#define GST_CAT_DEFAULT peaq_amd_debug
+
+#define PEAQ_CAPS "audio/x-raw, format = (string) F32LE, layout = (string) interleaved, rate = (int) 48000"
+
+typedef struct _GstPeaqAmd
+{
+  GstElement element;
+  GstPad *pads[2];              /* 0 = ref, 1 = test */
+  gboolean eos[2];
+  gboolean advanced;
+  gboolean console_output;
+  gdouble playback_level;
+  gint channels;
+  peaq_session *session;        /* NULL until caps are known */
+  gboolean failed;              /* a device error was reported already */
+} GstPeaqAmd;
+
+typedef struct _GstPeaqAmdClass
+{
+  GstElementClass parent_class;
+} GstPeaqAmdClass;
+
+enum
+{ PROP_0, PROP_PLAYBACK_LEVEL, PROP_ADVANCED, PROP_DI, PROP_ODG, PROP_TOTALSNR, PROP_CONSOLE_OUTPUT };
+
+static GstStaticPadTemplate ref_template =
+GST_STATIC_PAD_TEMPLATE ("ref", GST_PAD_SINK, GST_PAD_ALWAYS, GST_STATIC_CAPS (PEAQ_CAPS));
+static GstStaticPadTemplate test_template =
+GST_STATIC_PAD_TEMPLATE ("test", GST_PAD_SINK, GST_PAD_ALWAYS, GST_STATIC_CAPS (PEAQ_CAPS));
+
+GType gst_peaq_amd_get_type (void);
+G_DEFINE_TYPE (GstPeaqAmd, gst_peaq_amd, GST_TYPE_ELEMENT);
+#define GST_PEAQ_AMD(obj) ((GstPeaqAmd *) (obj))
+
+/* one device context per process */
+static peaq_ctx *
+shared_context (void)
+{
+  static gsize once = 0;
+  static peaq_ctx *ctx = NULL;
+  if (g_once_init_enter (&once)) {
+    const gchar *dev = g_getenv ("PEAQ_AMD_DEVICE");
+    if (peaq_ctx_create (dev ? atoi (dev) : 0, &ctx) != PEAQ_OK) {
+      GST_ERROR ("libpeaq_amd: %s", peaq_last_error ());
+      ctx = NULL;
+    }
+    g_once_init_leave (&once, 1);
+  }
+  return ctx;
+}
+
+/* (re)create the engine session: the reference re-allocates all per-channel state
+ * whenever caps or the `advanced` property change (gstpeaq.c:519,559,575,586) */
+static gboolean
+renew_session (GstPeaqAmd * self)
+{
+  peaq_ctx *ctx;
+  if (self->session) {
+    peaq_session_destroy (self->session);
+    self->session = NULL;
+  }
+  if (self->channels <= 0)
+    return TRUE;
+  ctx = shared_context ();
+  if (!ctx)
+    return FALSE;
+  if (peaq_session_create (ctx, self->advanced, self->channels, self->playback_level,
+          &self->session) != PEAQ_OK) {
+    GST_ELEMENT_ERROR (self, LIBRARY, INIT, ("libpeaq_amd: %s", peaq_last_error ()), (NULL));
+    return FALSE;
+  }
+  return TRUE;
+}
+
+static gboolean
+read_results (GstPeaqAmd * self, peaq_result * r)
+{
+  if (!self->session || peaq_session_results (self->session, r) != PEAQ_OK) {
+    gint i;
+    for (i = 0; i < PEAQ_MOVS_BASIC; i++)
+      r->movs[i] = NAN;
+    r->di = r->odg = r->totalsnr = NAN;      /* no data yet: the reference's empty accumulators give NaN too */
+    return FALSE;
+  }
+  return TRUE;
+}
+
+/* console text of the reference, gstpeaq.c:1023-1035,1051-1060,1075 */
+static void
+print_movs (const GstPeaqAmd * self, const peaq_result * r)
+{
+  const gdouble *m = r->movs;
+  if (!self->console_output)
+    return;
+  if (self->advanced)
+    g_print ("RmsModDiffA = %f\nRmsNoiseLoudAsymA = %f\nSegmentalNMRB = %f\nEHSB = %f\nAvgLinDistA = %f\n",
+        m[0], m[1], m[2], m[3], m[4]);
+  else
+    g_print ("   BandwidthRefB: %f\n  BandwidthTestB: %f\n      Total NMRB: %f\n"
+        "    WinModDiff1B: %f\n            ADBB: %f\n            EHSB: %f\n"
+        "    AvgModDiff1B: %f\n    AvgModDiff2B: %f\n   RmsNoiseLoudB: %f\n"
+        "           MFPDB: %f\n  RelDistFramesB: %f\n",
+        m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10]);
+}
+
+static gdouble
+evaluate_odg (GstPeaqAmd * self)
+{
+  peaq_result r;
+  read_results (self, &r);
+  print_movs (self, &r);
+  if (self->console_output)
+    g_print ("Objective Difference Grade: %.3f\n", r.odg);
+  return r.odg;
+}
+
+static void
+gst_peaq_amd_get_property (GObject * obj, guint id, GValue * value, GParamSpec * pspec)
+{
+  GstPeaqAmd *self = GST_PEAQ_AMD (obj);
+  peaq_result r;
+  switch (id) {
+    case PROP_PLAYBACK_LEVEL:
+      g_value_set_double (value, self->playback_level);
+      break;
+    case PROP_ADVANCED:
+      g_value_set_boolean (value, self->advanced);
+      break;
+    case PROP_CONSOLE_OUTPUT:
+      g_value_set_boolean (value, self->console_output);
+      break;
+    case PROP_DI:
+      read_results (self, &r);
+      print_movs (self, &r);
+      g_value_set_double (value, r.di);
+      break;
+    case PROP_ODG:
+      g_value_set_double (value, evaluate_odg (self));
+      break;
+    case PROP_TOTALSNR:
+      read_results (self, &r);
+      g_value_set_double (value, r.totalsnr);
+      break;
+    default:
+      G_OBJECT_WARN_INVALID_PROPERTY_ID (obj, id, pspec);
+  }
+}
+
+static void
+gst_peaq_amd_set_property (GObject * obj, guint id, const GValue * value, GParamSpec * pspec)
+{
+  GstPeaqAmd *self = GST_PEAQ_AMD (obj);
+  switch (id) {
+    case PROP_PLAYBACK_LEVEL:
+      GST_OBJECT_LOCK (self);
+      self->playback_level = g_value_get_double (value);
+      /* the level enters the constant level factors of both ear models
+       * (fftearmodel.c:305-314, fbearmodel.c:249-254); a running session keeps its level */
+      if (self->session && self->channels > 0)
+        GST_WARNING_OBJECT (self, "playback_level changed mid-stream: applies from the next (re)negotiation");
+      GST_OBJECT_UNLOCK (self);
+      break;
+    case PROP_ADVANCED:
+      GST_OBJECT_LOCK (self);
+      self->advanced = g_value_get_boolean (value);
+      if (self->channels > 0)
+        renew_session (self);
+      GST_OBJECT_UNLOCK (self);
+      break;
+    case PROP_CONSOLE_OUTPUT:
+      self->console_output = g_value_get_boolean (value);
+      break;
+    default:
+      G_OBJECT_WARN_INVALID_PROPERTY_ID (obj, id, pspec);
+  }
+}
+
+static gint
+pad_index (GstPeaqAmd * self, GstPad * pad)
+{
+  return pad == self->pads[0] ? 0 : 1;
+}
+
+static GstFlowReturn
+gst_peaq_amd_chain (GstPad * pad, GstObject * parent, GstBuffer * buffer)
+{
+  GstPeaqAmd *self = GST_PEAQ_AMD (parent);
+  GstMapInfo map;
+  GstFlowReturn ret = GST_FLOW_OK;
+  const gint idx = pad_index (self, pad);
+
+  if (!gst_buffer_map (buffer, &map, GST_MAP_READ)) {
+    gst_buffer_unref (buffer);
+    return GST_FLOW_ERROR;
+  }
+  GST_OBJECT_LOCK (self);               /* the two streaming threads are serialised, gstpeaq.c:619,658 */
+  self->eos[idx] = FALSE;
+  if (!self->session) {
+    ret = GST_FLOW_NOT_NEGOTIATED;
+  } else if (peaq_session_push (self->session, idx, (const float *) map.data,
+          map.size / (sizeof (float) * self->channels)) != PEAQ_OK) {
+    ret = GST_FLOW_ERROR;
+  }
+  GST_OBJECT_UNLOCK (self);
+  if (ret == GST_FLOW_ERROR && !self->failed) {
+    self->failed = TRUE;
+    GST_ELEMENT_ERROR (self, LIBRARY, FAILED, ("libpeaq_amd: %s", peaq_last_error ()), (NULL));
+  }
+  gst_buffer_unmap (buffer, &map);
+  gst_buffer_unref (buffer);           /* the samples were copied by the engine */
+  return ret;
+}
+
+static gboolean
+gst_peaq_amd_set_caps (GstPeaqAmd * self, GstCaps * caps)
+{
+  gint channels = 0;
+  gboolean ok = TRUE;
+  if (!gst_structure_get_int (gst_caps_get_structure (caps, 0), "channels", &channels) || channels < 1
+      || channels > 2) {
+    GST_ELEMENT_ERROR (self, CORE, NEGOTIATION, ("peaq handles mono or stereo, got %d channels", channels), (NULL));
+    return FALSE;
+  }
+  GST_OBJECT_LOCK (self);
+  if (channels != self->channels || !self->session) {
+    self->channels = channels;
+    ok = renew_session (self);
+  }
+  GST_OBJECT_UNLOCK (self);
+  return ok;
+}
+
+static gboolean
+gst_peaq_amd_sink_event (GstPad * pad, GstObject * parent, GstEvent * event)
+{
+  GstPeaqAmd *self = GST_PEAQ_AMD (parent);
+  const gint idx = pad_index (self, pad);
+  gboolean ret;
+  switch (GST_EVENT_TYPE (event)) {
+    case GST_EVENT_EOS:
+      /* a sink posts EOS once ALL its pads are at EOS (gstpeaq.c:668-688) */
+      self->eos[idx] = TRUE;
+      ret = TRUE;
+      if (self->eos[0] && self->eos[1]) {
+        GstMessage *msg = gst_message_new_eos (parent);
+        gst_message_set_seqnum (msg, gst_event_get_seqnum (event));
+        ret = gst_element_post_message (GST_ELEMENT (self), msg);
+      }
+      gst_event_unref (event);
+      return ret;
+    case GST_EVENT_CAPS:{
+      GstCaps *caps;
+      gst_event_parse_caps (event, &caps);
+      /* both inputs must carry the same number of channels: only accept what the
+       * other pad's upstream can also deliver (gstpeaq.c:689-708) */
+      ret = gst_pad_peer_query_accept_caps (self->pads[1 - idx], caps) && gst_peaq_amd_set_caps (self, caps);
+      gst_event_unref (event);
+      return ret;
+    }
+    default:
+      return gst_pad_event_default (pad, parent, event);
+  }
+}
+
+static gboolean
+gst_peaq_amd_sink_query (GstPad * pad, GstObject * parent, GstQuery * query)
+{
+  GstPeaqAmd *self = GST_PEAQ_AMD (parent);
+  if (GST_QUERY_TYPE (query) == GST_QUERY_CAPS) {
+    /* offer the template caps restricted to what the OTHER input can produce */
+    const gint idx = pad_index (self, pad);
+    GstCaps *filter, *tmpl, *other, *result;
+    gst_query_parse_caps (query, &filter);
+    tmpl = gst_pad_get_pad_template_caps (pad);
+    other = gst_pad_peer_query_caps (self->pads[1 - idx], filter);
+    result = gst_caps_intersect (tmpl, other);
+    gst_caps_unref (tmpl);
+    gst_caps_unref (other);
+    gst_query_set_caps_result (query, result);
+    gst_caps_unref (result);
+    return TRUE;
+  }
+  return gst_pad_query_default (pad, parent, query);
+}
+
+static GstStateChangeReturn
+gst_peaq_amd_change_state (GstElement * element, GstStateChange transition)
+{
+  GstPeaqAmd *self = GST_PEAQ_AMD (element);
+  if (transition == GST_STATE_CHANGE_PAUSED_TO_READY) {
+    /* do_flush + calculate_odg, gstpeaq.c:764-778 */
+    if (self->session && peaq_session_flush (self->session) != PEAQ_OK)
+      GST_ERROR_OBJECT (self, "libpeaq_amd: %s", peaq_last_error ());
+    evaluate_odg (self);
+  }
+  return GST_ELEMENT_CLASS (gst_peaq_amd_parent_class)->change_state (element, transition);
+}
+
+static void
+gst_peaq_amd_finalize (GObject * obj)
+{
+  GstPeaqAmd *self = GST_PEAQ_AMD (obj);
+  if (self->session)
+    peaq_session_destroy (self->session);
+  G_OBJECT_CLASS (gst_peaq_amd_parent_class)->finalize (obj);
+}
+
+static void
+gst_peaq_amd_class_init (GstPeaqAmdClass * klass)
+{
+  GObjectClass *oc = G_OBJECT_CLASS (klass);
+  GstElementClass *ec = GST_ELEMENT_CLASS (klass);
+
+  oc->get_property = gst_peaq_amd_get_property;
+  oc->set_property = gst_peaq_amd_set_property;
+  oc->finalize = gst_peaq_amd_finalize;
+  ec->change_state = gst_peaq_amd_change_state;
+
+  /* names, ranges and defaults as in gstpeaq.c:273-317 ("playback_level" with an underscore) */
+  g_object_class_install_property (oc, PROP_PLAYBACK_LEVEL,
+      g_param_spec_double ("playback_level", "playback level", "Playback level in dB", 0, 130, 92,
+          G_PARAM_READWRITE | G_PARAM_CONSTRUCT));
+  g_object_class_install_property (oc, PROP_ADVANCED,
+      g_param_spec_boolean ("advanced", "Advanced mode enabled", "True if advanced mode is used", FALSE,
+          G_PARAM_READWRITE | G_PARAM_CONSTRUCT));
+  g_object_class_install_property (oc, PROP_DI,
+      g_param_spec_double ("di", "distortion index", "Distortion Index", -G_MAXDOUBLE, G_MAXDOUBLE, 0,
+          G_PARAM_READABLE));
+  g_object_class_install_property (oc, PROP_ODG,
+      g_param_spec_double ("odg", "objective difference grade", "Objective Difference Grade", -G_MAXDOUBLE,
+          G_MAXDOUBLE, 0, G_PARAM_READABLE));
+  g_object_class_install_property (oc, PROP_TOTALSNR,
+      g_param_spec_double ("totalsnr", "the overall SNR in dB", "the overall signal to noise ratio in dB",
+          -G_MAXDOUBLE, G_MAXDOUBLE, 0, G_PARAM_READABLE));
+  g_object_class_install_property (oc, PROP_CONSOLE_OUTPUT,
+      g_param_spec_boolean ("console-output", "console output", "Enable or disable console output", TRUE,
+          G_PARAM_READWRITE | G_PARAM_CONSTRUCT));
+
+  gst_element_class_add_static_pad_template (ec, &ref_template);
+  gst_element_class_add_static_pad_template (ec, &test_template);
+  gst_element_class_set_static_metadata (ec, "Perceptual evaluation of audio quality (MI355X)", "Sink/Audio",
+      "Compute objective audio quality measures (ITU-R BS.1387) on an AMD GPU", "gstpeaq_amd");
+}
+
+static void
+gst_peaq_amd_init (GstPeaqAmd * self)
+{
+  static GstStaticPadTemplate *tmpl[2] = { &ref_template, &test_template };
+  gint i;
+  for (i = 0; i < 2; i++) {
+    self->pads[i] = gst_pad_new_from_static_template (tmpl[i], i ? "test" : "ref");
+    gst_pad_set_chain_function (self->pads[i], gst_peaq_amd_chain);
+    gst_pad_set_event_function (self->pads[i], gst_peaq_amd_sink_event);
+    gst_pad_set_query_function (self->pads[i], gst_peaq_amd_sink_query);
+    gst_element_add_pad (GST_ELEMENT (self), self->pads[i]);
+  }
+  GST_OBJECT_FLAG_SET (self, GST_ELEMENT_FLAG_SINK);
+  self->channels = 0;
+  self->session = NULL;
+  self->failed = FALSE;
+}
+
+static gboolean
+plugin_init (GstPlugin * plugin)
+{
+  GST_DEBUG_CATEGORY_INIT (peaq_amd_debug, "peaq", 0, "PEAQ on MI355X");
+  return gst_element_register (plugin, "peaq", GST_RANK_NONE, gst_peaq_amd_get_type ());
+}
+
+GST_PLUGIN_DEFINE (GST_VERSION_MAJOR, GST_VERSION_MINOR, peaq,
+    "Perceptual evaluation of audio quality (ITU-R BS.1387) on AMD MI355X",
+    plugin_init, PACKAGE_VERSION, "LGPL", PACKAGE, "https://github.com/HSU-ANT/gstpeaq")
