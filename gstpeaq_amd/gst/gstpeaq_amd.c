@@ -59,8 +59,12 @@ GST_STATIC_PAD_TEMPLATE ("ref", GST_PAD_SINK, GST_PAD_ALWAYS, GST_STATIC_CAPS (P
 static GstStaticPadTemplate test_template =
 GST_STATIC_PAD_TEMPLATE ("test", GST_PAD_SINK, GST_PAD_ALWAYS, GST_STATIC_CAPS (PEAQ_CAPS));
 
+/* registered under the reference's type name "GstPeaq" so that unnamed instances
+ * are called peaq0, peaq1, ... as before */
+typedef GstPeaqAmd GstPeaq;
+typedef GstPeaqAmdClass GstPeaqClass;
 GType gst_peaq_amd_get_type (void);
-G_DEFINE_TYPE (GstPeaqAmd, gst_peaq_amd, GST_TYPE_ELEMENT);
+G_DEFINE_TYPE_WITH_CODE (GstPeaq, gst_peaq_amd, GST_TYPE_ELEMENT,);
 #define GST_PEAQ_AMD(obj) ((GstPeaqAmd *) (obj))
 
 /* one device context per process */

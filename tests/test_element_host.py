@@ -30,7 +30,9 @@ def test_properties():
     # gstpeaq.c:273-317 (GObject shows playback_level in its canonical form)
     for prop in ("playback-level", "advanced", "console-output", "di ", "odg ", "totalsnr"):
         assert prop in txt, prop
-    assert "Default: 92" in txt
+    import re
+    assert re.search(r"Range:\s+0 -\s+130 Default:\s+92", txt)       # playback_level: 0..130, default 92
+    assert 'Default: "peaq0"' in txt                                 # instances are named like the reference's
 
 
 def test_cli_usage_and_exit_codes(tmp_path):
