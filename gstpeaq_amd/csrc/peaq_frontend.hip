@@ -354,23 +354,43 @@ __global__ __launch_bounds__(128) void frontend_kernel(FrontendArgs a) {
 
   __syncthreads();                                   // both spectra are in LDS
   const double* p_ref = lds + kOffP;
-  const double* p_test = lds + kUnitDoubles + kOffP;
+  double* p_test = lds + kUnitDoubles + kOffP;
   const double* pw_ref = lds + kOffPw;
   const double* pw_test = lds + kUnitDoubles + kOffPw;
+  double* dlog = lds + kOffScratch;                          // [512] shared: ln(Pw_test / Pw_ref)
+  double* cbuf = lds + kUnitDoubles + kOffScratch;           // [256] shared: correlation by lag
+
+  // ---- error harmonic structure, part 1 (movs.c:1383-1391): both waves, 256 bins each ----
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = 256 * sig + lane + 64 * j;
+    const double fr = pw_ref[k], ft = pw_test[k];
+    dlog[k] = (fr == 0. && ft == 0.) ? 0. : log(ft / fr);
+  }
+  __syncthreads();
+  // ---- part 2: c[l] = sum_{k<256} d[k] d[k+l]  (the reference evaluates the same sums through
+  // 512-point FFTs, movs.c:1279-1315).  Each wave takes 128 lags, a lane the lag pair
+  // (l0, l0+1) with l0 even; two k per step so that every LDS read is an aligned 16-byte one.
+  {
+    const int l0 = 128 * sig + 2 * lane;
+    double c0 = 0., c1 = 0.;
+    double2 w = *reinterpret_cast<const double2*>(dlog + l0);          // d[k+l0], d[k+l0+1] at k = 0
+#pragma unroll 8
+    for (int k = 0; k < 256; k += 2) {
+      const double2 dk = *reinterpret_cast<const double2*>(dlog + k);  // broadcast
+      // next window; the very last one of lag pair (254,255) would start at index 512: unused, clamped
+      const double2 wn = *reinterpret_cast<const double2*>(dlog + min(k + 2 + l0, 510));
+      c0 = fma(dk.x, w.x, c0);
+      c1 = fma(dk.x, w.y, c1);
+      c0 = fma(dk.y, w.y, c0);
+      c1 = fma(dk.y, wn.x, c1);
+      w = wn;
+    }
+    *reinterpret_cast<double2*>(cbuf + l0) = make_double2(c0, c1);
+  }
+  __syncthreads();
 
   if (sig == 1) {
-    // ---- noise in bands for the NMR MOVs (movs.c:992-1000) -----------------------
-    double nib[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int b = b0 + s;
-      nib[s] = b < NB ? group_band(bt, b, [&](int k) {
-        const double r = pw_ref[k], t = pw_test[k];
-        return r - 2 * sqrt(r * t) + t;
-      }) : 0.;
-    }
-    if (b0 < kBandStride) *reinterpret_cast<double2*>(rec + kRecNoise + b0) = make_double2(nib[0], nib[1]);
-
     // ---- bandwidths (movs.c:776-809), unweighted spectrum ------------------------
     double thr = 0.;                                 // powers are >= 0
     for (int k = 921 + lane; k < 1024; k += 64) thr = fmax(thr, p_test[k]);
@@ -385,6 +405,21 @@ __global__ __launch_bounds__(128) void frontend_kernel(FrontendArgs a) {
         if (p_test[k] >= 3.16227766016838 * thr) bw_test = k + 1;
       bw_test = wave_max_i(bw_test);
     }
+    // ---- noise spectrum for the NMR MOVs (movs.c:992-996): one bin per lane and step,
+    // overwriting this unit's (now dead) unweighted spectrum; then the band grouping ---------
+    wave_lds_fence();
+    for (int k = lane; k < kPwLen; k += 64) {
+      const double r = pw_ref[k], t = pw_test[k];
+      p_test[k] = r - 2 * sqrt(r * t) + t;
+    }
+    wave_lds_fence();
+    double nib[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int b = b0 + s;
+      nib[s] = b < NB ? group_band(bt, b, [&](int k) { return p_test[k]; }) : 0.;
+    }
+    if (b0 < kBandStride) *reinterpret_cast<double2*>(rec + kRecNoise + b0) = make_double2(nib[0], nib[1]);
     // ---- totalsnr energies over the hop (gstpeaq.c:913-918; float products) --------
     double se = 0., ne = 0.;
 #pragma unroll
@@ -407,24 +442,11 @@ __global__ __launch_bounds__(128) void frontend_kernel(FrontendArgs a) {
       rec[kRecNoiseE] = ne;
     }
   } else {
-    // ---- error harmonic structure (movs.c:1346-1443), per frame and channel ---------
-    // d[k] = ln(Pw_test/Pw_ref), k < 512
-    double* d = scratch;                             // [512]
+    // ---- error harmonic structure, part 3 (movs.c:1393-1441): lane owns lags lane + 64 m ----
+    double* d = dlog;
+    double c[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = lane + 64 * j;
-      const double fr = pw_ref[k], ft = pw_test[k];
-      d[k] = (fr == 0. && ft == 0.) ? 0. : log(ft / fr);
-    }
-    wave_lds_fence();
-    // c[l] = sum_{k<256} d[k] d[k+l]; lane owns lags lane + 64 m.  (The reference
-    // evaluates the same sums through 512-point FFTs, movs.c:1279-1315.)
-    double c[4] = {0., 0., 0., 0.};
-    for (int k = 0; k < 256; ++k) {
-      const double dk = d[k];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) c[m] = fma(dk, d[k + lane + 64 * m], c[m]);
-    }
+    for (int m = 0; m < 4; ++m) c[m] = cbuf[lane + 64 * m];
     const double d0 = __shfl(c[0], 0, 64);
     // running window energy dk[l] = d0 + sum_{j<l} (d[j+256]^2 - d[j]^2)   (:1413-1418)
     {
