@@ -243,7 +243,7 @@ __device__ __forceinline__ double total_loudness(const BandLane<NB, SLOTS>& bl, 
     if (bl.valid(s)) {
       const int b = bl.band(s);
       const double thr = bt->threshold[b];
-      const double l = bt->loud_factor[b] * (pow(1. - thr + thr * exc[s] / bt->exc_threshold[b], 0.23) - 1.);
+      const double l = bt->loud_factor[b] * (pow_pos(1. - thr + thr * exc[s] / bt->exc_threshold[b], 0.23) - 1.);
       t += fmax(l, 0.);
     }
   }
@@ -264,8 +264,8 @@ __device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, 
       const double stest = thres_fac * mod_test[s] + s0;
       const double ethres = bt->internal_noise[bl.band(s)];
       const double beta = exp(-alpha * (e_test[s] - e_ref[s]) / e_ref[s]);
-      nl += pow(ethres / stest, 0.23) *
-            (pow(1. + fmax(stest * e_test[s] - sref * e_ref[s], 0.) / (ethres + sref * e_ref[s] * beta), 0.23) - 1.);
+      nl += pow_pos(ethres / stest, 0.23) *
+            (pow_pos(1. + fmax(stest * e_test[s] - sref * e_ref[s], 0.) / (ethres + sref * e_ref[s] * beta), 0.23) - 1.);
     }
   }
   nl = wave_sum(nl) * (24. / NB);
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(128) void backend_kernel(BackendArgs a) {
           const double et_db = 10. * log10(et[s]);
           const double l = 0.3 * fmax(er_db, et_db) + 0.7 * et_db;
           const double l2 = l * l;
-          const double sd = l > 0. ? 5.95072 * pow(6.39468 / l, 1.71332) + 9.01033e-11 * l2 * l2 +
+          const double sd = l > 0. ? 5.95072 * pow_pos(6.39468 / l, 1.71332) + 9.01033e-11 * l2 * l2 +
                                          5.05622e-6 * l2 * l - 0.00102438 * l * l + 0.0550197 * l - 0.198719
                                    : 1e30;
           const double e = er_db - et_db;
@@ -642,8 +642,8 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
     ut[0] = rec[kFbRecUnsmTest + lb];
     er[0] = rec[kFbRecExcRef + lb];
     et[0] = rec[kFbRecExcTest + lb];
-    lr[0] = pow(ur[0], 0.3);                         // modpatt.c:235
-    lt[0] = pow(ut[0], 0.3);
+    lr[0] = pow_pos(ur[0], 0.3);                     // modpatt.c:235
+    lt[0] = pow_pos(ut[0], 0.3);
     double ad_ref[SLOTS], ad_test[SLOTS], mr[SLOTS], mt[SLOTS];
     level_adapt<NB, SLOTS>(bl, bt, er, et, la, &sh.pa[chan][0][0], ad_ref, ad_test);
     modulation<NB, SLOTS>(bl, bt, lr, mdr, mr);

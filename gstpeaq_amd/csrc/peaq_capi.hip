@@ -106,7 +106,8 @@ struct peaq_ctx {
   FbTables* d_fb = nullptr;
   std::mutex mu;            // serialises batch calls / workspace use
   // batch workspace
-  DevBuf records, fb_records, state, fbstate, hp_scratch, counts;
+  DevBuf records, records2, fb_records, state, fbstate, hp_scratch, counts;
+  hipStream_t aux = nullptr;   // the back end runs here, overlapped with the next chunk's front end
   hipEvent_t batch_begin = nullptr, batch_end = nullptr;
   bool batch_pending = false;
   std::vector<TimedSpan> spans;
@@ -158,6 +159,7 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
   }
   HIP_TRY(hipEventCreate(&c->batch_begin));
   HIP_TRY(hipEventCreate(&c->batch_end));
+  HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
   *out = c;
   return PEAQ_OK;
 }
@@ -172,6 +174,8 @@ extern "C" void peaq_ctx_destroy(peaq_ctx* c) {
   (void)hipFree(c->d_bands40);
   (void)hipFree(c->d_fb);
   c->records.release();
+  c->records2.release();
+  if (c->aux) (void)hipStreamDestroy(c->aux);
   c->fb_records.release();
   c->state.release();
   c->fbstate.release();
@@ -204,7 +208,7 @@ static unsigned frames_per_chunk(int n_pairs, int channels, uint32_t max_frames)
 extern "C" size_t peaq_batch_workspace_bytes(int advanced, int channels, int n_pairs, uint32_t n_max) {
   const uint32_t frames = count_frames(n_max, n_max, kFrame, kHop);
   const unsigned fc = frames_per_chunk(n_pairs, channels, frames);
-  size_t b = (size_t)n_pairs * fc * channels * kRecDoubles * sizeof(double) + (size_t)n_pairs * sizeof(PairState) +
+  size_t b = 2 * (size_t)n_pairs * fc * channels * kRecDoubles * sizeof(double) + (size_t)n_pairs * sizeof(PairState) +
              (size_t)n_pairs * 4 * sizeof(uint32_t);
   if (advanced) {
     const unsigned bc = kFbBlocksPerChunk;
@@ -266,7 +270,9 @@ extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double le
   }
 
   const unsigned fc = frames_per_chunk(n_pairs, channels, max_frames);
-  HIP_TRY(c->records.reserve((size_t)n_pairs * fc * channels * kRecDoubles * sizeof(double)));
+  const size_t rec_bytes = (size_t)n_pairs * fc * channels * kRecDoubles * sizeof(double);
+  HIP_TRY(c->records.reserve(rec_bytes));
+  HIP_TRY(c->records2.reserve(rec_bytes));
   HIP_TRY(c->state.reserve((size_t)n_pairs * sizeof(PairState)));
 
   HIP_TRY(hipEventRecord(c->batch_begin, stream));
@@ -289,9 +295,7 @@ extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double le
   fa.level_factor = fft_level_factor(level_db);
   fa.common = c->d_common;
   fa.bands = advanced ? c->d_bands55 : c->d_bands109;    // gstpeaq.c:521-526
-  fa.records = c->records.as<double>();
   BackendArgs ba{};
-  ba.records = fa.records;
   ba.n_frames = d_nframes;
   ba.n_frames_uniform = max_frames;
   ba.channels = channels;
@@ -299,22 +303,37 @@ extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double le
   ba.bands = fa.bands;
   ba.state = c->state.as<PairState>();
 
-  for (uint32_t f0 = 0; f0 < max_frames; f0 += fc) {
+  // Software pipeline over chunks of frames: the front end of chunk i+1 (throughput bound,
+  // millions of workgroups) runs on the caller's stream while the back end of chunk i
+  // (one workgroup per pair, latency bound) runs on the context's second stream; the
+  // per-frame records are double buffered.
+  hipEvent_t back_done[2] = {nullptr, nullptr};
+  unsigned chunk = 0;
+  for (uint32_t f0 = 0; f0 < max_frames; f0 += fc, ++chunk) {
     const unsigned nf = std::min<uint32_t>(fc, max_frames - f0);
+    double* recs = (chunk & 1) ? c->records2.as<double>() : c->records.as<double>();
     fa.frame0 = f0;
     fa.frames_per_launch = nf;
+    fa.records = recs;
     ba.frame0 = f0;
     ba.frames_per_launch = nf;
-    hipEvent_t e0 = c->next_event(), e1 = c->next_event(), e2 = c->next_event();
-    if (!e0 || !e1 || !e2) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
+    ba.records = recs;
+    hipEvent_t e0 = c->next_event(), e1 = c->next_event(), e2 = c->next_event(), e3 = c->next_event();
+    if (!e0 || !e1 || !e2 || !e3) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
+    if (back_done[chunk & 1]) HIP_TRY(hipStreamWaitEvent(stream, back_done[chunk & 1], 0));   // buffer free again
     HIP_TRY(hipEventRecord(e0, stream));
     HIP_TRY(launch_frontend(advanced ? 55 : 109, fa, n_pairs, stream));
     HIP_TRY(hipEventRecord(e1, stream));
-    HIP_TRY(launch_backend(ba, n_pairs, stream));
-    HIP_TRY(hipEventRecord(e2, stream));
+    HIP_TRY(hipStreamWaitEvent(c->aux, e1, 0));
+    HIP_TRY(hipEventRecord(e2, c->aux));
+    HIP_TRY(launch_backend(ba, n_pairs, c->aux));
+    HIP_TRY(hipEventRecord(e3, c->aux));
+    back_done[chunk & 1] = e3;
     c->spans.push_back({e0, e1, 0});
-    c->spans.push_back({e1, e2, 1});
+    c->spans.push_back({e2, e3, 1});
   }
+  for (int i = 0; i < 2; ++i)
+    if (back_done[i]) HIP_TRY(hipStreamWaitEvent(stream, back_done[i], 0));
   if (advanced && max_blocks > 0) {
     // ---- filter-bank path: blocks of 192 samples (gstpeaq.c:648-652) ------------------
     const unsigned n_signals = (unsigned)n_pairs * channels * 2;

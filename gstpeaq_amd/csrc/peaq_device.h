@@ -50,6 +50,7 @@ struct BandTables {             // earmodel.c:279-323 + fftearmodel.c:693-788
   double ln_aUC[kBandStride];
   double gIL[kBandStride];
   double inv_spread_norm[kBandStride];
+  double inv_spread_norm_pow03[kBandStride];   // inv_spread_norm^0.3 (for E^0.3)
   double mask_diff[kBandStride];
 };
 

@@ -40,6 +40,18 @@ constexpr int kOffPw = 1024;                  // Pw[776]
 constexpr int kOffScratch = 1800;             // 512 doubles
 constexpr int kPwLen = 776;
 
+// W_32^q = exp(-2 pi i q / 32), q = 0..15
+__device__ constexpr double kW32re[16] = {1., 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                                          0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173,
+                                          0.19509032201612826785, 0., -0.19509032201612826785, -0.38268343236508977173,
+                                          -0.55557023301960222474, -0.70710678118654752440, -0.83146961230254523708,
+                                          -0.92387953251128675613, -0.98078528040323044913};
+__device__ constexpr double kW32im[16] = {-0., -0.19509032201612826785, -0.38268343236508977173, -0.55557023301960222474,
+                                          -0.70710678118654752440, -0.83146961230254523708, -0.92387953251128675613,
+                                          -0.98078528040323044913, -1., -0.98078528040323044913, -0.92387953251128675613,
+                                          -0.83146961230254523708, -0.70710678118654752440, -0.55557023301960222474,
+                                          -0.38268343236508977173, -0.19509032201612826785};
+
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }   // complex index -> padded slot
 
 __device__ __forceinline__ cplx lds_ldc(const double* base, int idx) {
@@ -67,10 +79,22 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double* unit
     const int k = lane & 15;
 #pragma unroll
     for (int r = 0; r < 16; ++r) z[r] = lds_ldc(unit, lane + 64 * r);
+    {
+      // twiddles W_256^(r k) = W_2048^(8 r k), r = 1..15: four table reads (r = 1, 2, 4, 8),
+      // the rest as products -- 4 instead of 15 trips to L2 per lane
+      cplx w[16];
+      w[1] = {ct->tw_re[8 * k], ct->tw_im[8 * k]};
+      w[2] = {ct->tw_re[16 * k], ct->tw_im[16 * k]};
+      w[4] = {ct->tw_re[32 * k], ct->tw_im[32 * k]};
+      w[8] = {ct->tw_re[64 * k], ct->tw_im[64 * k]};
+      w[3] = cmul(w[1], w[2]);
+      w[5] = cmul(w[4], w[1]);
+      w[6] = cmul(w[4], w[2]);
+      w[7] = cmul(w[4], w[3]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) {
-      const int t = 8 * r * k;                         // W_256^(r k) = W_2048^(8 r k)
-      z[r] = cmul(z[r], {ct->tw_re[t], ct->tw_im[t]});
+      for (int r = 1; r < 8; ++r) w[8 + r] = cmul(w[8], w[r]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) z[r] = cmul(z[r], w[r]);
     }
     dft16(z);
     const int j = (lane - k) * 16 + k;
@@ -87,11 +111,12 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double* unit
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int i = lane + 64 * m;
-#pragma unroll
-    for (int r = 1; r < 4; ++r) {
-      const int t = 2 * r * i;                         // W_1024^(r i) = W_2048^(2 r i)
-      z[m + 4 * r] = cmul(z[m + 4 * r], {ct->tw_re[t], ct->tw_im[t]});
-    }
+    // W_1024^(r i) = W_2048^(2 r i), r = 1..3: one table read, two products
+    const cplx w1 = {ct->tw_re[2 * i], ct->tw_im[2 * i]};
+    const cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+    z[m + 4] = cmul(z[m + 4], w1);
+    z[m + 8] = cmul(z[m + 8], w2);
+    z[m + 12] = cmul(z[m + 12], w3);
     dft4(z[m], z[m + 4], z[m + 8], z[m + 12]);
   }
   // z[q] = Z[lane + 64 q].  Publish, then fetch the mirror bins Z[1024 - k].
@@ -103,13 +128,16 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double* unit
 #pragma unroll
   for (int q = 0; q < 16; ++q) zm[q] = lds_ldc(unit, (1024 - (lane + 64 * q)) & 1023);
   wave_lds_fence();
-  // even/odd split: X[k] = E[k] + W_2048^k O[k]
+  // even/odd split: X[k] = E[k] + W_2048^k O[k], k = lane + 64 q:
+  // W_2048^k = W_2048^lane * W_32^q, the second factor is a compile-time constant
+  const cplx wl = {ct->tw_re[lane], ct->tw_im[lane]};
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int k = lane + 64 * q;
     const cplx e = {0.5 * (z[q].re + zm[q].re), 0.5 * (z[q].im - zm[q].im)};
     const cplx o = {0.5 * (z[q].im + zm[q].im), -0.5 * (z[q].re - zm[q].re)};
-    const cplx x = cadd(e, cmul({ct->tw_re[k], ct->tw_im[k]}, o));
+    const cplx wq = {kW32re[q], kW32im[q]};
+    const cplx x = cadd(e, cmul(q == 0 ? wl : cmul(wl, wq), o));
     const double p = (x.re * x.re + x.im * x.im) * level_factor;     // fftearmodel.c:464-466
     unit[kOffP + k] = p;
     if (k < kPwLen) unit[kOffPw + k] = p * ct->ear_w2[k];             // fftearmodel.c:470-472
@@ -294,7 +322,7 @@ __global__ __launch_bounds__(128) void frontend_kernel(FrontendArgs a) {
       const double g_iu = (1. - exp((double)(NB - b) * ln_a)) / (1. - a_uce);
       const double en = pp / (bt->gIL[b] + g_iu - 1.);
       ae[s] = exp(0.4 * ln_a);
-      ene[s] = pow(en, 0.4);
+      ene[s] = pow_pos(en, 0.4);
     } else {
       ae[s] = 0.;
       ene[s] = 0.;
@@ -336,10 +364,12 @@ __global__ __launch_bounds__(128) void frontend_kernel(FrontendArgs a) {
   for (int s = 0; s < 2; ++s) {
     const int b = b0 + s;
     const double e2 = (s ? dn1 : dn0) + e2up[b < NB ? b : 0];
-    // (25): E2^(1/0.4) / normalisation; x^2.5 = x^2 sqrt(x)
-    const double e = e2 * e2 * sqrt(e2) * bt->inv_spread_norm[b < NB ? b : 0];
-    unsm[s] = b < NB ? e : 0.;
-    loud[s] = b < NB ? pow(e, 0.3) : 0.;             // modpatt.c:235
+    // (25): E = E2^(1/0.4) / normalisation, and E^0.3 for the modulation patterns (modpatt.c:235),
+    // both from square roots: x^2.5 = x^2 sqrt(x), (x^2.5)^0.3 = x^0.75 = sqrt(x) sqrt(sqrt(x))
+    const int bb = b < NB ? b : 0;
+    const double r1 = sqrt(e2), r2 = sqrt(r1);
+    unsm[s] = b < NB ? e2 * e2 * r1 * bt->inv_spread_norm[bb] : 0.;
+    loud[s] = b < NB ? r1 * r2 * bt->inv_spread_norm_pow03[bb] : 0.;
   }
   if (b0 < kBandStride) {
     *reinterpret_cast<double2*>(rec + (sig ? kRecUnsmTest : kRecUnsmRef) + b0) = make_double2(unsm[0], unsm[1]);

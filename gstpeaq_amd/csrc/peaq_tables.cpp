@@ -127,13 +127,17 @@ void build_fft_band_tables(int bands, BandTables& t) {
   fill_common_bands(t, fc, n / 2, 1.07664, 0.008, 0.030);  // fftearmodel.c:53,224-228
   std::vector<double> ones(bands, 1.0), norm;
   spread_reference_order(t, aUC, ones, norm);
-  for (int i = 0; i < bands; ++i) t.inv_spread_norm[i] = 1.0 / norm[i];
+  for (int i = 0; i < bands; ++i) {
+    t.inv_spread_norm[i] = 1.0 / norm[i];
+    t.inv_spread_norm_pow03[i] = std::pow(t.inv_spread_norm[i], 0.3);
+  }
   for (int i = bands; i < kBandStride; ++i) {
     t.lo[i] = t.hi[i] = 0;
     t.wlo[i] = t.whi[i] = 0.0;
     t.ln_aUC[i] = -1.0;
     t.gIL[i] = 1.0;
     t.inv_spread_norm[i] = 0.0;
+    t.inv_spread_norm_pow03[i] = 0.0;
     t.mask_diff[i] = 1.0;
   }
 }
