@@ -79,6 +79,7 @@ def load_library():
     L.peaq_synth_fill.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_size_t, vp, vp, vp]
     L.peaq_debug_frontend.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp, vp, C.c_uint32, C.c_uint32,
                                       C.c_int, dp]
+    L.peaq_debug_filterbank.argtypes = [vp, C.c_int, C.c_double, vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, dp]
     _LIB = L
     return L
 
@@ -217,4 +218,18 @@ def debug_frontend(ctx, bands, ref, test, n_frames, playback_level=92.0):
     _check(ctx.L.peaq_debug_frontend(ctx.h, bands, channels, float(playback_level), C.c_void_p(ref.data_ptr()),
                                      C.c_void_p(test.data_ptr()), ref.shape[0], test.shape[0], n_frames,
                                      out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def debug_filterbank(ctx, ref, test, n_blocks, blocks_per_launch=320, playback_level=92.0):
+    """Stage-level access to the filter-bank ear model of ONE pair.
+    ref/test: CUDA float32 [n, channels].  -> np [blocks, channels, 168]"""
+    import torch
+    assert ref.is_cuda and test.is_cuda and ref.is_contiguous() and test.is_contiguous()
+    channels = ref.shape[1]
+    out = np.zeros((n_blocks, channels, 168))
+    torch.cuda.synchronize()
+    _check(ctx.L.peaq_debug_filterbank(ctx.h, channels, float(playback_level), C.c_void_p(ref.data_ptr()),
+                                       C.c_void_p(test.data_ptr()), ref.shape[0], test.shape[0], n_blocks,
+                                       blocks_per_launch, out.ctypes.data_as(C.POINTER(C.c_double))))
     return out

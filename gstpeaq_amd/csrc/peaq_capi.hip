@@ -478,6 +478,61 @@ extern "C" int peaq_debug_frontend(peaq_ctx* c, int bands, int channels, double 
   return PEAQ_OK;
 }
 
+extern "C" int peaq_debug_filterbank(peaq_ctx* c, int channels, double level_db, const float* d_ref,
+                                     const float* d_test, uint32_t n_ref, uint32_t n_test, int n_blocks,
+                                     int blocks_per_launch, double* host_out) {
+  if (!c || !d_ref || !d_test || !host_out) return fail(PEAQ_ERR_ARG, "peaq_debug_filterbank: NULL argument");
+  if (channels != 1 && channels != 2) return fail(PEAQ_ERR_ARG, "peaq_debug_filterbank: channels must be 1 or 2");
+  const uint32_t total = count_frames(n_ref, n_test, kFbFrame, kFbFrame);
+  if (n_blocks < 0 || (uint32_t)n_blocks > total || blocks_per_launch < 1)
+    return fail(PEAQ_ERR_ARG, "peaq_debug_filterbank: bad block counts");
+  if (n_blocks == 0) return PEAQ_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const unsigned n_signals = 2 * channels;
+  const size_t row_stride = (size_t)kFbRing + (size_t)blocks_per_launch * kFbFrame;
+  DevBuf rows, recs, st;
+  HIP_TRY(rows.reserve(n_signals * row_stride * sizeof(double)));
+  HIP_TRY(recs.reserve((size_t)blocks_per_launch * channels * kFbRecDoubles * sizeof(double)));
+  HIP_TRY(st.reserve(n_signals * sizeof(FbSignalState)));
+  HIP_TRY(hipMemset(st.p, 0, n_signals * sizeof(FbSignalState)));
+  FbFrontArgs ff{};
+  ff.ref = d_ref;
+  ff.test = d_test;
+  ff.pair_stride = std::max(n_ref, n_test);
+  ff.n_uniform_ref = n_ref;
+  ff.n_uniform_test = n_test;
+  ff.n_blocks_uniform = n_blocks;
+  ff.channels = channels;
+  ff.level_factor = fb_level_factor(level_db);
+  ff.bands = c->d_bands40;
+  ff.fb = c->d_fb;
+  ff.fbstate = st.as<FbSignalState>();
+  ff.hp_scratch = rows.as<double>();
+  ff.hp_row_stride = row_stride;
+  ff.records = recs.as<double>();
+  hipError_t e = hipSuccess;
+  unsigned prev = 0;
+  for (int b0 = 0; b0 < n_blocks && e == hipSuccess; b0 += blocks_per_launch) {
+    const unsigned nb = std::min(blocks_per_launch, n_blocks - b0);
+    ff.block0 = b0;
+    ff.blocks_per_launch = nb;
+    ff.prev_blocks = prev;
+    ff.first_launch = b0 == 0;
+    e = hipMemset(recs.p, 0, recs.cap);
+    if (e == hipSuccess) e = launch_fb_frontend(ff, 1, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+      e = hipMemcpy(host_out + (size_t)b0 * channels * kFbRecDoubles, recs.p,
+                    (size_t)nb * channels * kFbRecDoubles * sizeof(double), hipMemcpyDeviceToHost);
+    prev = nb;
+  }
+  rows.release();
+  recs.release();
+  st.release();
+  if (e != hipSuccess) return fail(PEAQ_ERR_DEVICE, std::string("peaq_debug_filterbank: ") + hipGetErrorString(e));
+  return PEAQ_OK;
+}
+
 // ---------------------------------------------------------------------------
 // sessions: one per `peaq` element instance
 // ---------------------------------------------------------------------------

@@ -61,6 +61,7 @@ struct FbTables {               // fbearmodel.c:57-61,182-225
   double back_mask[6];
   double h_re[12000];           // sum(N/2+1) = 10954 coefficients
   double h_im[12000];
+  double h_ri[24000];           // the same, interleaved {re, im} per tap (one 16-byte load per tap)
 };
 
 // ---- per-frame record: front end -> back end --------------------------------

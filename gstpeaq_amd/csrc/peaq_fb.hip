@@ -146,73 +146,159 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
 }
 
 // ---------------------------------------------------------------------------
-// kernel 2: filter bank, spreading, masking
+// kernel 2: filter bank, spreading, masking.  One workgroup of four waves per
+// signal; a tile is 60 sub-samples (10 blocks).  Phase 1 (the bulk of the work):
+// every wave evaluates 10 of the 40 complex FIR filters for all 60 time points
+// (lane = time point) from the shared window in LDS; the bands are dealt out so
+// that the four waves carry the same number of taps.  Phases 2..5 turn the 40 x 60
+// filter outputs into excitation patterns.
 // ---------------------------------------------------------------------------
 constexpr int kTileSub = 60;                        // sub-samples per tile (10 blocks)
 constexpr int kTileBlocks = 10;
 constexpr int kWin = (kTileSub - 1) * 32 + kFbRing + 1;   // 3345 filtered samples
 constexpr int kWinCols = (kWin + 31) / 32;          // 105
 constexpr int kWinRow = kWinCols + 1;               // row stride in doubles (106)
+constexpr int kACols = 64;                          // A[band][time] row stride
+
+// window sample with uniform index part u (the lane adds its time point): row u mod 32,
+// column u div 32 -- lanes (time points 32 samples apart) then sit in consecutive columns
+__host__ __device__ constexpr int win_off(int u) { return (u & 31) * kWinRow + (u >> 5); }
 
 struct BankLds {
-  double win[32 * kWinRow];        // window sample w at [(w & 31)][w >> 5]
+  union {
+    double win[32 * kWinRow];                       // phase 1
+    struct {
+      double re[kFbBands][kACols];                  // phases 2..4: A[band][time]
+      double im[kFbBands][kACols];
+    } a;
+  };
   double e1[kFbBands][kTileBlocks];
   double hist[kFbBands][10];       // the 10 newest E0 values of the previous tile, oldest first
-  double e0row[kTileSub + 10];
   double cu[kFbBands];
 };
 
-// one band's complex FIR at this lane's time point (fbearmodel.c:404-434)
+// One band's complex FIR at this lane's time point (fbearmodel.c:404-434).
+// win_t = window + t.  Taps are consumed in groups of 8: 16 LDS reads and 8 coefficient
+// loads are issued back to back, then the 32 multiply-adds; all LDS offsets inside a
+// 32-tap macro step are compile-time constants.
 template <int B>
-__device__ __forceinline__ void fir_band(const double* __restrict__ win, int t, const FbTables* __restrict__ fb,
+__device__ __forceinline__ void fir_band(const double* __restrict__ win_t, const double2* __restrict__ coef,
                                          double& re_out, double& im_out) {
   constexpr int N = kLen[B];
   constexpr int D = 1 + (kLen[0] - N) / 2;           // (31) in BS.1387
   constexpr int H = N / 2;
-  const double* __restrict__ hr = fb->h_re + coef_offset(B);
-  const double* __restrict__ hi = fb->h_im + coef_offset(B);
-  // window index of the sample delayed by m: kFbRing + 32 t - m
-  auto X = [&](int u) {                              // u = kFbRing - m (wave-uniform part)
-    return win[(u & 31) * kWinRow + (u >> 5) + t];
-  };
+  constexpr int U1 = kFbRing - D;                    // x1(n): u = U1 - n   (delay D + n)
+  constexpr int U2 = kFbRing - D - N;                // x2(n): u = U2 + n   (delay D + N - n)
+  constexpr int FULL = (H - 1) / 32;
+  constexpr int REM = (H - 1) - 32 * FULL;
+  const double2* __restrict__ hc = coef + coef_offset(B);
   double re = 0., im = 0.;
-  int n = 1;
-  if (B == 0) {
-    // the reference's doubled ring buffer makes band 0's delay-1456 tap read the
-    // NEWEST sample (fb_buf[offset + 1456] aliases fb_buf[offset]); reproduced
-    const double x1 = X(kFbRing - (D + 1)), x2 = X(kFbRing - 0);
-    re += (x1 + x2) * hr[1];
-    im += (x1 - x2) * hi[1];
-    n = 2;
+  // One group = 8 taps: 8 coefficient pairs arrive through the scalar cache (wave-uniform
+  // address -> s_load, and v_fma_f64 takes them straight from SGPRs), 16 samples from LDS.
+  // GROUP_FENCE makes the group's addresses depend on the accumulators of the previous
+  // group: without it the compiler hoists the loads of a whole filter to the top and spills
+  // them (the loads are independent of the arithmetic).  Latency is covered by the other
+  // waves of the SIMD (3 resident), not by pipelining inside the wave.
+#define GROUP_FENCE(ptr) asm volatile("" : "+s"(ptr), "+v"(re), "+v"(im))
+#pragma unroll 1
+  for (int q = 0; q < FULL; ++q) {
+    // n = 1 + 32 q + r: moving 32 taps on shifts the column by one, the row pattern repeats
+    const double* p1 = win_t - q;
+    const double* p2 = win_t + q;
+    const double2* c = hc + 1 + 32 * q;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      GROUP_FENCE(c);
+      double a[8], b[8];
+      double2 cc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * g + j;
+        a[j] = p1[win_off(U1 - 1 - r)];
+        // the reference's doubled ring buffer makes band 0's delay-1456 tap (n = 1) read the
+        // NEWEST sample (fb_buf[offset + 1456] aliases fb_buf[offset]); reproduced
+        b[j] = (B == 0 && r == 0) ? (q == 0 ? win_t[win_off(kFbRing)] : p2[win_off(U2 + 1 + r)])
+                                  : p2[win_off(U2 + 1 + r)];
+        cc[j] = c[r];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        re = fma(a[j] + b[j], cc[j].x, re);          // even symmetry
+        im = fma(a[j] - b[j], cc[j].y, im);          // odd symmetry
+      }
+    }
   }
-#pragma unroll 8
-  for (; n < H; ++n) {
-    const double x1 = X(kFbRing - (D + n)), x2 = X(kFbRing - (D + N - n));
-    re += (x1 + x2) * hr[n];                         // even symmetry
-    im += (x1 - x2) * hi[n];                         // odd symmetry
+  if (REM > 0) {
+    const double* p1 = win_t - FULL;
+    const double* p2 = win_t + FULL;
+    const double2* c = hc + 1 + 32 * FULL;
+#pragma unroll
+    for (int g = 0; g < (REM + 7) / 8; ++g) {
+      GROUP_FENCE(c);
+      double a[8], b[8];
+      double2 cc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * g + j;
+        if (r < REM) {
+          a[j] = p1[win_off(U1 - 1 - r)];
+          b[j] = (B == 0 && FULL == 0 && r == 0) ? win_t[win_off(kFbRing)] : p2[win_off(U2 + 1 + r)];
+          cc[j] = c[r];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * g + j;
+        if (r < REM) {
+          re = fma(a[j] + b[j], cc[j].x, re);
+          im = fma(a[j] - b[j], cc[j].y, im);
+        }
+      }
+    }
   }
-  const double xm = X(kFbRing - (D + H));
-  re_out = re + xm * hr[H];
-  im_out = im + xm * hi[H];
+  const double2* hcv = hc + H;
+  GROUP_FENCE(hcv);
+#undef GROUP_FENCE
+  const double xm = win_t[win_off(U1 - H)];          // centre tap, once
+  const double2 ch = *hcv;
+  re_out = fma(xm, ch.x, re);
+  im_out = fma(xm, ch.y, im);
 }
 
-template <int B>
-struct FirAll {
-  __device__ __forceinline__ static void run(const double* win, int t, const FbTables* fb, double (&re)[kFbBands],
-                                             double (&im)[kFbBands]) {
-    fir_band<B>(win, t, fb, re[B], im[B]);
-    FirAll<B + 1>::run(win, t, fb, re, im);
-  }
-};
-template <>
-struct FirAll<kFbBands> {
-  __device__ __forceinline__ static void run(const double*, int, const FbTables*, double (&)[kFbBands],
-                                             double (&)[kFbBands]) {}
-};
+// the ten bands of wave w: { w, 7-w, 8+w, 15-w, 16+w, 23-w, 24+w, 31-w, 32+w, 39-w } --
+// a longest-first deal of the filter lengths: 2728 tap pairs per wave
+template <int W>
+__device__ __forceinline__ void fir_wave(const double* win_t, const double2* coef, double (&re)[10], double (&im)[10]) {
+  // scheduling fences: the ten filters are independent, without them the scheduler overlaps
+  // their load phases and runs out of registers
+  fir_band<W>(win_t, coef, re[0], im[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  fir_band<7 - W>(win_t, coef, re[1], im[1]);
+  __builtin_amdgcn_sched_barrier(0);
+  fir_band<8 + W>(win_t, coef, re[2], im[2]);
+  __builtin_amdgcn_sched_barrier(0);
+  fir_band<15 - W>(win_t, coef, re[3], im[3]);
+  __builtin_amdgcn_sched_barrier(0);
+  fir_band<16 + W>(win_t, coef, re[4], im[4]);
+  __builtin_amdgcn_sched_barrier(0);
+  fir_band<23 - W>(win_t, coef, re[5], im[5]);
+  __builtin_amdgcn_sched_barrier(0);
+  fir_band<24 + W>(win_t, coef, re[6], im[6]);
+  __builtin_amdgcn_sched_barrier(0);
+  fir_band<31 - W>(win_t, coef, re[7], im[7]);
+  __builtin_amdgcn_sched_barrier(0);
+  fir_band<32 + W>(win_t, coef, re[8], im[8]);
+  __builtin_amdgcn_sched_barrier(0);
+  fir_band<39 - W>(win_t, coef, re[9], im[9]);
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ int wave_band(int w, int i) { return (i & 1) ? 8 * (i >> 1) + 7 - w : 8 * (i >> 1) + w; }
 
-__global__ __launch_bounds__(64) void fb_bank_kernel(FbFrontArgs a, unsigned n_signals) {
+__global__ __launch_bounds__(256, 3) void fb_bank_kernel(FbFrontArgs a, unsigned n_signals) {
   __shared__ BankLds sh;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: say so
   const unsigned g = blockIdx.x;
   const int sig = g & 1;
   const int chan = (g >> 1) % a.channels;
@@ -222,20 +308,21 @@ __global__ __launch_bounds__(64) void fb_bank_kernel(FbFrontArgs a, unsigned n_s
   const unsigned nb_mine = min(a.blocks_per_launch, n_blocks - a.block0);
   const BandTables* __restrict__ bt = a.bands;
   const FbTables* __restrict__ fb = a.fb;
+  const double2* __restrict__ coef = reinterpret_cast<const double2*>(fb->h_ri);
   const size_t row_len = a.hp_row_stride;
   const size_t row_valid = (size_t)kFbRing + (size_t)a.blocks_per_launch * kFbFrame;
   const double* __restrict__ row = a.hp_scratch + (size_t)g * row_len;
   FbSignalState* __restrict__ st = a.fbstate + g;
 
   // recurrent state -> LDS / registers
-  if (lane < kFbBands) {
-    sh.cu[lane] = st->cu[lane];
+  if (tid < kFbBands) {
+    sh.cu[tid] = st->cu[tid];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) sh.hist[lane][i] = st->e0_hist[lane][i];
+    for (int i = 0; i < 10; ++i) sh.hist[tid][i] = st->e0_hist[tid][i];
   }
-  double exc = lane < kFbBands ? st->excitation[lane] : 0.;
+  double exc = tid < kFbBands ? st->excitation[tid] : 0.;
   // (1-A)^(t+1): decay of the slope-filter state that enters a tile
-  double decay = 1. - kSlopeA;
+  double decay;
   {
     double p = 1. - kSlopeA, acc = 1.;
     int e = lane + 1;
@@ -246,32 +333,49 @@ __global__ __launch_bounds__(64) void fb_bank_kernel(FbFrontArgs a, unsigned n_s
     }
     decay = acc;
   }
-  wave_lds_fence();
+  const int t = lane < kTileSub ? lane : kTileSub - 1;
 
   for (unsigned b0 = 0; b0 < nb_mine; b0 += kTileBlocks) {
     const unsigned nvb = min((unsigned)kTileBlocks, nb_mine - b0);   // valid blocks in this tile
     const int nvs = 6 * nvb;                                         // valid sub-samples
-    // ---- window of the filtered signal: samples [192 b0 - 1456, 192 b0 + 59*32] ---------
+    __syncthreads();                                                 // previous tile is done with the LDS
+    // ---- phase 0: window of the filtered signal, samples [192 b0 - 1456, 192 b0 + 59*32] ------
     {
       const double* src = row + (size_t)b0 * kFbFrame;               // row index 0 = sample -1456 of the launch
       const int avail = (int)min((size_t)kWin, row_valid - (size_t)b0 * kFbFrame);
-      for (int wdx = lane; wdx < kWin; wdx += 64)
-        sh.win[(wdx & 31) * kWinRow + (wdx >> 5)] = wdx < avail ? src[wdx] : 0.;
+      for (int wdx = tid; wdx < kWin; wdx += 256) sh.win[win_off(wdx)] = wdx < avail ? src[wdx] : 0.;
     }
-    wave_lds_fence();
-    // ---- 40 complex FIR filters at sample 32 t (lane t) ----------------------------------
-    double re[kFbBands], im[kFbBands];
-    const int t = lane < kTileSub ? lane : kTileSub - 1;
-    FirAll<0>::run(sh.win, t, fb, re, im);
-
-    // ---- spreading (fbearmodel.c:327-354); bands in DESCENDING order so that the
-    // accumulation can run in place: band b only receives from bands below it -------------
+    __syncthreads();
+    // ---- phase 1: the complex FIR filters (fbearmodel.c:399-435) ---------------------------------
+    double re[10], im[10];
+    {
+      const double* win_t = sh.win + t;
+      switch (wv) {
+        case 0: fir_wave<0>(win_t, coef, re, im); break;
+        case 1: fir_wave<1>(win_t, coef, re, im); break;
+        case 2: fir_wave<2>(win_t, coef, re, im); break;
+        default: fir_wave<3>(win_t, coef, re, im); break;
+      }
+    }
+    __syncthreads();                                                 // everybody is done with the window
+    // ---- phase 2a: A = filter outputs (overlays the window) ----------------------------------------
 #pragma unroll
-    for (int b = kFbBands - 1; b >= 0; --b) {
-      const double level = 10. * log10(re[b] * re[b] + im[b] * im[b]);
+    for (int i = 0; i < 10; ++i) {
+      const int b = wave_band(wv, i);
+      sh.a.re[b][lane] = re[i];
+      sh.a.im[b][lane] = im[i];
+    }
+    __syncthreads();
+    // ---- phase 2b: level-dependent upward spreading (fbearmodel.c:327-349).  The slope
+    // filter runs along time = along the lanes (inclusive scan with the carried-in state);
+    // every source band adds its geometric tail into the bands above it with LDS atomics
+    // (one column per lane: no contention inside an instruction) -----------------------------------
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int b = wave_band(wv, i);
+      const double level = 10. * log10(re[i] * re[i] + im[i] * im[i]);
       const double slope = fmax(4., 24. + 230. / bt->fc[b] - 0.2 * level);
       const double dist_s = exp(slope * kLnDist);                    // pow(DIST, s)
-      // cu[t] = cu[t-1] + A (dist_s[t] - cu[t-1]): inclusive scan over the time lanes
       double v = kSlopeA * dist_s, m = 1. - kSlopeA;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -281,63 +385,87 @@ __global__ __launch_bounds__(64) void fb_bank_kernel(FbFrontArgs a, unsigned n_s
       }
       const double cu = v + decay * sh.cu[b];
       const double carry = __shfl(cu, nvs - 1, 64);
-      wave_lds_fence();
-      if (lane == 0) sh.cu[b] = carry;
-      if (b < kFbBands - 1) {
-        double d1 = re[b], d2 = im[b];
+      if (lane == 0) sh.cu[b] = carry;                               // only this wave touches cu[b]
+      double d1 = re[i], d2 = im[i];
+      for (int j = b + 1; j < kFbBands; ++j) {
+        d1 *= cu;
+        d2 *= cu;
+        atomicAdd(&sh.a.re[j][lane], d1);
+        atomicAdd(&sh.a.im[j][lane], d2);
+      }
+    }
+    __syncthreads();
+    // ---- phase 3: downward spreading (fbearmodel.c:351-354): wave 0 the real, wave 1 the
+    // imaginary parts; a column per lane ----------------------------------------------------------
+    if (wv < 2) {
+      double (*A)[kACols] = wv == 0 ? sh.a.re : sh.a.im;
+      double acc = A[kFbBands - 1][lane];
+#pragma unroll 13
+      for (int b = kFbBands - 1; b > 0; --b) {
+        acc = A[b - 1][lane] + kCL * acc;
+        A[b - 1][lane] = acc;
+      }
+    }
+    __syncthreads();
+    // ---- phase 4: rectification + backward masking at block rate (fbearmodel.c:357-382);
+    // one (band, block) per thread --------------------------------------------------------------------
+    for (int item = tid; item < kFbBands * kTileBlocks; item += 256) {
+      const int b = item / kTileBlocks, blk = item - b * kTileBlocks;
+      // E0 of sub-sample s (negative: previous tile)
+      auto e0 = [&](int s) {
+        if (s < 0) return sh.hist[b][10 + s];
+        const double x = sh.a.re[b][s], y = sh.a.im[b][s];
+        return x * x + y * y;
+      };
+      const int s_new = 6 * blk + 5;                 // newest sub-sample of the block
+      double e1 = 0.;
 #pragma unroll
-        for (int j = b + 1; j < kFbBands; ++j) {
-          d1 *= cu;
-          d2 *= cu;
-          re[j] += d1;
-          im[j] += d2;
+      for (int i = 0; i < 5; ++i) e1 += (e0(s_new - i) + e0(s_new - 10 + i)) * fb->back_mask[i];
+      e1 += e0(s_new - 5) * fb->back_mask[5];
+      sh.e1[b][blk] = e1;
+    }
+    __syncthreads();
+    // history for the next tile: the 10 newest VALID sub-samples, oldest first
+    // (400 (band, slot) items on 256 threads: two per thread)
+    double hnew[2] = {0., 0.};
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int item = tid + 256 * rep;
+      if (item < kFbBands * 10) {
+        const int b = item / 10, k = item - b * 10;
+        const int s = nvs - 10 + k;
+        if (s < 0) {
+          hnew[rep] = sh.hist[b][10 + s];
+        } else {
+          const double x = sh.a.re[b][s], y = sh.a.im[b][s];
+          hnew[rep] = x * x + y * y;
         }
       }
     }
+    __syncthreads();
 #pragma unroll
-    for (int b = kFbBands - 1; b > 0; --b) {
-      re[b - 1] += kCL * re[b];
-      im[b - 1] += kCL * im[b];
+    for (int rep = 0; rep < 2; ++rep) {
+      const int item = tid + 256 * rep;
+      if (item < kFbBands * 10) sh.hist[item / 10][item % 10] = hnew[rep];
     }
-    // ---- rectification + backward masking (fbearmodel.c:357-382) ---------------------------
-#pragma unroll
-    for (int b = 0; b < kFbBands; ++b) {
-      const double e0 = re[b] * re[b] + im[b] * im[b];
-      wave_lds_fence();
-      if (lane < 10) sh.e0row[lane] = sh.hist[b][lane];
-      if (lane < kTileSub) sh.e0row[10 + lane] = e0;
-      wave_lds_fence();
-      if (lane < kTileBlocks) {
-        // newest sample of block `lane` is sub-sample 6 lane + 5 -> e0row[6 lane + 15]
-        const double* p = sh.e0row + 6 * lane + 15;
-        double e1 = 0.;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) e1 += (p[-i] + p[-(10 - i)]) * fb->back_mask[i];
-        e1 += p[-5] * fb->back_mask[5];
-        sh.e1[b][lane] = e1;
-      }
-      // history for the next tile: the 10 newest VALID sub-samples, oldest first
-      if (lane < 10) sh.hist[b][lane] = sh.e0row[nvs + lane];
-    }
-    wave_lds_fence();
-    // ---- internal noise + forward masking (fbearmodel.c:385-394), lanes = bands -------------
-    if (lane < kFbBands) {
-      const double noise = bt->internal_noise[lane], ac = bt->ear_tc[lane];
+    // ---- phase 5: internal noise + forward masking (fbearmodel.c:385-394), thread = band ------------
+    if (tid < kFbBands) {
+      const double noise = bt->internal_noise[tid], ac = bt->ear_tc[tid];
       for (unsigned bl = 0; bl < nvb; ++bl) {
-        const double unsm = sh.e1[lane][bl] + noise;
+        const double unsm = sh.e1[tid][bl] + noise;
         exc = ac * exc + (1. - ac) * unsm;
         double* rec = a.records + ((size_t)(pair * a.blocks_per_launch + b0 + bl) * a.channels + chan) * kFbRecDoubles;
-        rec[(sig ? kFbRecUnsmTest : kFbRecUnsmRef) + lane] = unsm;
-        rec[(sig ? kFbRecExcTest : kFbRecExcRef) + lane] = exc;
+        rec[(sig ? kFbRecUnsmTest : kFbRecUnsmRef) + tid] = unsm;
+        rec[(sig ? kFbRecExcTest : kFbRecExcRef) + tid] = exc;
       }
     }
-    wave_lds_fence();
   }
-  if (lane < kFbBands) {
-    st->cu[lane] = sh.cu[lane];
+  __syncthreads();
+  if (tid < kFbBands) {
+    st->cu[tid] = sh.cu[tid];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) st->e0_hist[lane][i] = sh.hist[lane][i];
-    st->excitation[lane] = exc;
+    for (int i = 0; i < 10; ++i) st->e0_hist[tid][i] = sh.hist[tid][i];
+    st->excitation[tid] = exc;
   }
 }
 
@@ -347,7 +475,7 @@ hipError_t launch_fb_frontend(const FbFrontArgs& a, unsigned n_pairs, hipStream_
   hipLaunchKernelGGL(fb_hp_kernel, dim3((n_signals + 63) / 64), dim3(64), 0, stream, a, n_signals);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fb_bank_kernel, dim3(n_signals), dim3(64), 0, stream, a, n_signals);
+  hipLaunchKernelGGL(fb_bank_kernel, dim3(n_signals), dim3(256), 0, stream, a, n_signals);
   return hipGetLastError();
 }
 

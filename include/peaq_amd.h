@@ -157,6 +157,15 @@ int peaq_debug_frontend (peaq_ctx *ctx, int bands, int channels, double playback
                          const float *d_ref, const float *d_test, uint32_t n_ref, uint32_t n_test,
                          int n_frames, double *host_out);
 
+/* The same for the filter-bank ear model (advanced): per-block records
+ *   out[block][channel][PEAQ_DEBUG_FB_RECORD_DOUBLES] =
+ *   { unsmeared ref[40], unsmeared test[40], excitation ref[40], excitation test[40],
+ *     above-threshold flag, pad[7] } */
+#define PEAQ_DEBUG_FB_RECORD_DOUBLES 168
+int peaq_debug_filterbank (peaq_ctx *ctx, int channels, double playback_level_db,
+                           const float *d_ref, const float *d_test, uint32_t n_ref, uint32_t n_test,
+                           int n_blocks, int blocks_per_launch, double *host_out);
+
 #ifdef __cplusplus
 }
 #endif

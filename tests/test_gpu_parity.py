@@ -87,6 +87,32 @@ def test_frontend_records_match_oracle(gpu, bands, case):
     np.testing.assert_allclose(got[:, :, 565:567], exp[:, :, 565:567], rtol=1e-12, atol=0, err_msg="energies")
 
 
+@pytest.mark.parametrize("bpl", [320, 7])
+@pytest.mark.parametrize("case", [
+    dict(kind="synth", seed=5, channels=1, n=30000),
+    dict(kind="synth", seed=6, channels=2, n=25000, test_trim=1000),
+    dict(kind="ats", wave_ref="saw", wave_test="triangle", n=20000, channels=1),
+], ids=["mono", "stereo-ragged", "saw-triangle"])
+def test_filterbank_records_match_oracle(gpu, case, bpl):
+    """stage-level, advanced: unsmeared + forward-masked excitation of the 40-band filter bank per
+    192-sample block (fbearmodel.c:276-396) and the block boundary flag, for whole-chunk launches
+    and for launches of 7 blocks (state, delay line and histories carried between launches)"""
+    import torch
+    import gstpeaq_amd
+    ref, test = case_defs.make_inputs(case)
+    ch = ref.shape[1]
+    n = min(len(ref), len(test))
+    n_blocks = n // 192
+    got = gstpeaq_amd.debug_filterbank(gpu.ctx(), torch.from_numpy(ref).cuda(), torch.from_numpy(test).cuda(),
+                                       n_blocks, bpl)
+    for c in range(ch):
+        for name, sig, lo in (("ref", ref, 0), ("test", test, 40)):
+            exp = orc.fbear(np.ascontiguousarray(sig[:, c]), n_blocks)
+            np.testing.assert_allclose(got[:, c, lo:lo + 40], exp["unsmeared"], rtol=1e-9, err_msg=f"unsmeared {name} ch{c}")
+            np.testing.assert_allclose(got[:, c, 80 + lo:120 + lo], exp["excitation"], rtol=1e-9,
+                                       err_msg=f"excitation {name} ch{c}")
+
+
 @pytest.mark.parametrize("channels", [1, 2])
 def test_batch_basic_matches_reference_goldens(gpu, channels):
     """every basic-mode end-to-end case of tests/golden/ref_e2e.json (outputs of the
