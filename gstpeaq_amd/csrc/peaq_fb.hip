@@ -180,9 +180,11 @@ struct BankLds {
 // One band's complex FIR at this lane's time point (fbearmodel.c:404-434).
 // win_t = window + t.  Taps are consumed in groups of 8; all LDS offsets inside a 32-tap
 // macro step are compile-time constants.  Software pipeline: while group G is evaluated
-// (16 LDS reads, 16 add/sub, 16 fma) the 8 coefficient pairs of group G+1 are already in
-// flight from L2 through the vector memory pipe (global_load: its own counter, so waiting
-// for the LDS reads does not wait for them).
+// (16 LDS reads, 16 add/sub, 16 fma) the 8 coefficient pairs of group G+1 are requested
+// through the SCALAR cache (the address is wave-uniform; v_fma_f64 takes the coefficient
+// straight from an SGPR pair).  Broadcast loads through the vector memory pipe cost a full
+// 64-lane transaction each and saturated the texture addresser (measured: 1.4e9 VMEM
+// instructions per launch = the whole kernel time).
 // A plain ds_read_b64 moves 256 B/clk/CU, the merged ds_read2_b64 the compiler likes to form
 // only 128 (MI355X_MICROARCH.md, LDS table): read the window through volatile accesses so that
 // every sample is its own ds_read_b64 with an immediate offset.
@@ -191,7 +193,7 @@ __device__ __forceinline__ double lds_rd(const double* p) {
 }
 
 typedef double v2d __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(1))) v2d* gcoef_t;
+typedef const __attribute__((address_space(4))) v2d* gcoef_t;
 
 template <int B>
 __device__ __forceinline__ void fir_band(const double* __restrict__ win_t, const double2* __restrict__ coef,
