@@ -98,18 +98,38 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
   }
   HpWalk w{st->hp[0], st->hp[1], st->hp[2], st->hp[3], st->hp[4], st->hp[5]};
 
+  // samples are fetched 16 ahead of their use: the walk itself is a chain of dependent FP64
+  // operations, the loads (one cache line per lane) must never be waited for
+  auto fetch = [&](unsigned bl, int k, bool mine) -> float {
+    const long long s = (long long)(a.block0 + bl - a.block_origin) * kFbFrame + off + k;
+    return (mine && s < (long long)n_sig) ? x[s * a.channels] : 0.f;   // zero padding: gstpeaq.c:733-738
+  };
+  float xq[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) xq[j] = fetch(0, j, 0 < nb_mine);
   for (unsigned bl = 0; bl < nb_max; ++bl) {
     const bool mine = bl < nb_mine;
-    const long long s0 = (long long)(a.block0 + bl - a.block_origin) * kFbFrame + off;
     float sum = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;   // |x| of the last five samples
     int above = 0;
     for (int k0 = 0; k0 < kFbFrame; k0 += 8) {
       double y[8];
+      float xin[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xin[j] = xq[j];
+        xq[j] = xq[j + 8];
+      }
+      {                                              // refill: samples k0+16 .. k0+23 (may be the next block)
+        const int kn = k0 + 16;
+        const unsigned bln = kn < kFbFrame ? bl : bl + 1;
+        const int kk = kn < kFbFrame ? kn : kn - kFbFrame;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xq[8 + j] = fetch(bln, kk + j, bln < nb_mine);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = k0 + j;
-        const long long s = s0 + k;
-        const float xv = (mine && s < (long long)n_sig) ? x[s * a.channels] : 0.f;   // zero padding: gstpeaq.c:733-738
+        const float xv = xin[j];
         y[j] = w.step((double)xv * a.level_factor);
         // gstpeaq.c:1083-1096: FLOAT running sum, tested from i = 5 on
         const float ax = fabsf(xv);
