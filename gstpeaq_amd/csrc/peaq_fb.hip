@@ -144,7 +144,9 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
       // 64 x 8 transpose through LDS: each store instruction writes 64-byte runs
 #pragma unroll
       for (int j = 0; j < 8; ++j) tile[lane][j] = y[j];
-      __syncthreads();
+      // the workgroup is ONE wave: LDS is in program order, no barrier needed -- and
+      // __syncthreads() would drain the prefetched loads and the stores (vmcnt(0)) every 8 samples
+      wave_lds_fence();
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int src = r * 8 + (lane >> 3);
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
         if (gs < n_signals && a.block0 + bl < nbs)
           rows[(size_t)gs * row_len + kFbRing + (size_t)bl * kFbFrame + k0 + (lane & 7)] = tile[src][lane & 7];
       }
-      __syncthreads();
+      wave_lds_fence();
     }
     if (mine && sig == 0)
       a.records[((size_t)(pair * a.blocks_per_launch + bl) * a.channels + chan) * kFbRecDoubles + kFbRecFlags] =
