@@ -108,6 +108,7 @@ struct peaq_ctx {
   // batch workspace
   DevBuf records, records2, fb_records, state, fbstate, hp_scratch, counts;
   hipStream_t aux = nullptr;   // the back end runs here, overlapped with the next chunk's front end
+  hipStream_t aux2 = nullptr;  // advanced: the filter-bank path runs here, beside the FFT path
   hipEvent_t batch_begin = nullptr, batch_end = nullptr;
   bool batch_pending = false;
   std::vector<TimedSpan> spans;
@@ -160,6 +161,7 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
   HIP_TRY(hipEventCreate(&c->batch_begin));
   HIP_TRY(hipEventCreate(&c->batch_end));
   HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
   *out = c;
   return PEAQ_OK;
 }
@@ -176,6 +178,7 @@ extern "C" void peaq_ctx_destroy(peaq_ctx* c) {
   c->records.release();
   c->records2.release();
   if (c->aux) (void)hipStreamDestroy(c->aux);
+  if (c->aux2) (void)hipStreamDestroy(c->aux2);
   c->fb_records.release();
   c->state.release();
   c->fbstate.release();
@@ -216,6 +219,64 @@ extern "C" size_t peaq_batch_workspace_bytes(int advanced, int channels, int n_p
     b += (size_t)n_pairs * channels * 2 * (sizeof(FbSignalState) + ((size_t)bc * kFbFrame + kFbRing) * sizeof(double));
   }
   return b;
+}
+
+static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n_pairs, const float* d_ref,
+                               const float* d_test, size_t pair_stride, const uint32_t* d_nref,
+                               const uint32_t* d_ntest, uint32_t n_uniform, const uint32_t* d_nblocks,
+                               uint32_t max_blocks, hipStream_t stream) {
+    // ---- filter-bank path: blocks of 192 samples (gstpeaq.c:648-652) ------------------
+    const unsigned n_signals = (unsigned)n_pairs * channels * 2;
+    const unsigned bc = std::min<unsigned>(kFbBlocksPerChunk, (max_blocks + 9) / 10 * 10);
+    const size_t row_stride = (size_t)kFbRing + (size_t)bc * kFbFrame;
+    HIP_TRY(c->hp_scratch.reserve((size_t)n_signals * row_stride * sizeof(double)));
+    HIP_TRY(c->fb_records.reserve((size_t)n_pairs * bc * channels * kFbRecDoubles * sizeof(double)));
+    HIP_TRY(c->fbstate.reserve((size_t)n_signals * sizeof(FbSignalState)));
+    HIP_TRY(hipMemsetAsync(c->fbstate.p, 0, (size_t)n_signals * sizeof(FbSignalState), stream));
+    FbFrontArgs ff{};
+    ff.ref = d_ref;
+    ff.test = d_test;
+    ff.pair_stride = pair_stride;
+    ff.n_ref = d_nref;
+    ff.n_test = d_ntest;
+    ff.n_uniform_ref = ff.n_uniform_test = n_uniform;
+    ff.n_blocks = d_nblocks;
+    ff.n_blocks_uniform = max_blocks;
+    ff.block_origin = 0;
+    ff.channels = channels;
+    ff.level_factor = fb_level_factor(level_db);
+    ff.bands = c->d_bands40;
+    ff.fb = c->d_fb;
+    ff.fbstate = c->fbstate.as<FbSignalState>();
+    ff.hp_scratch = c->hp_scratch.as<double>();
+    ff.hp_row_stride = row_stride;
+    ff.records = c->fb_records.as<double>();
+    FbBackendArgs fbk{};
+    fbk.records = ff.records;
+    fbk.n_blocks = d_nblocks;
+    fbk.n_blocks_uniform = max_blocks;
+    fbk.channels = channels;
+    fbk.bands = c->d_bands40;
+    fbk.state = c->state.as<PairState>();
+    unsigned prev = 0;
+    for (uint32_t b0 = 0; b0 < max_blocks; b0 += bc) {
+      const unsigned nb = std::min<uint32_t>(bc, max_blocks - b0);
+      ff.block0 = b0;
+      ff.blocks_per_launch = nb;
+      ff.prev_blocks = prev;
+      ff.first_launch = b0 == 0;
+      fbk.block0 = b0;
+      fbk.blocks_per_launch = nb;
+      hipEvent_t e0 = c->next_event(), e1 = c->next_event();
+      if (!e0 || !e1) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
+      HIP_TRY(hipEventRecord(e0, stream));
+      HIP_TRY(launch_fb_frontend(ff, n_pairs, stream));
+      HIP_TRY(launch_fb_backend(fbk, n_pairs, stream));
+      HIP_TRY(hipEventRecord(e1, stream));
+      c->spans.push_back({e0, e1, 2});
+      prev = nb;
+    }
+  return PEAQ_OK;
 }
 
 extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double level_db, int n_pairs,
@@ -277,6 +338,21 @@ extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double le
 
   HIP_TRY(hipEventRecord(c->batch_begin, stream));
   HIP_TRY(launch_state_init(c->state.as<PairState>(), advanced, n_pairs, stream));
+  hipEvent_t fb_done = nullptr;
+  if (advanced && max_blocks > 0) {
+    // the filter-bank path (its own ear model, accumulators 0, 1, 4) is independent of the FFT
+    // path (accumulators 2, 3): it runs on a third stream from here on and joins at the end
+    hipEvent_t forked = c->next_event();
+    if (!forked) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(forked, stream));
+    HIP_TRY(hipStreamWaitEvent(c->aux2, forked, 0));
+    const int rc = run_filterbank_path(c, channels, level_db, n_pairs, d_ref, d_test, pair_stride, d_nref, d_ntest,
+                                       n_uniform, d_nblocks, max_blocks, c->aux2);
+    if (rc != PEAQ_OK) return rc;
+    fb_done = c->next_event();
+    if (!fb_done) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(fb_done, c->aux2));
+  }
 
   FrontendArgs fa{};
   fa.ref = d_ref;
@@ -334,59 +410,7 @@ extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double le
   }
   for (int i = 0; i < 2; ++i)
     if (back_done[i]) HIP_TRY(hipStreamWaitEvent(stream, back_done[i], 0));
-  if (advanced && max_blocks > 0) {
-    // ---- filter-bank path: blocks of 192 samples (gstpeaq.c:648-652) ------------------
-    const unsigned n_signals = (unsigned)n_pairs * channels * 2;
-    const unsigned bc = std::min<unsigned>(kFbBlocksPerChunk, (max_blocks + 9) / 10 * 10);
-    const size_t row_stride = (size_t)kFbRing + (size_t)bc * kFbFrame;
-    HIP_TRY(c->hp_scratch.reserve((size_t)n_signals * row_stride * sizeof(double)));
-    HIP_TRY(c->fb_records.reserve((size_t)n_pairs * bc * channels * kFbRecDoubles * sizeof(double)));
-    HIP_TRY(c->fbstate.reserve((size_t)n_signals * sizeof(FbSignalState)));
-    HIP_TRY(hipMemsetAsync(c->fbstate.p, 0, (size_t)n_signals * sizeof(FbSignalState), stream));
-    FbFrontArgs ff{};
-    ff.ref = d_ref;
-    ff.test = d_test;
-    ff.pair_stride = pair_stride;
-    ff.n_ref = d_nref;
-    ff.n_test = d_ntest;
-    ff.n_uniform_ref = ff.n_uniform_test = n_uniform;
-    ff.n_blocks = d_nblocks;
-    ff.n_blocks_uniform = max_blocks;
-    ff.block_origin = 0;
-    ff.channels = channels;
-    ff.level_factor = fb_level_factor(level_db);
-    ff.bands = c->d_bands40;
-    ff.fb = c->d_fb;
-    ff.fbstate = c->fbstate.as<FbSignalState>();
-    ff.hp_scratch = c->hp_scratch.as<double>();
-    ff.hp_row_stride = row_stride;
-    ff.records = c->fb_records.as<double>();
-    FbBackendArgs fbk{};
-    fbk.records = ff.records;
-    fbk.n_blocks = d_nblocks;
-    fbk.n_blocks_uniform = max_blocks;
-    fbk.channels = channels;
-    fbk.bands = c->d_bands40;
-    fbk.state = c->state.as<PairState>();
-    unsigned prev = 0;
-    for (uint32_t b0 = 0; b0 < max_blocks; b0 += bc) {
-      const unsigned nb = std::min<uint32_t>(bc, max_blocks - b0);
-      ff.block0 = b0;
-      ff.blocks_per_launch = nb;
-      ff.prev_blocks = prev;
-      ff.first_launch = b0 == 0;
-      fbk.block0 = b0;
-      fbk.blocks_per_launch = nb;
-      hipEvent_t e0 = c->next_event(), e1 = c->next_event();
-      if (!e0 || !e1) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
-      HIP_TRY(hipEventRecord(e0, stream));
-      HIP_TRY(launch_fb_frontend(ff, n_pairs, stream));
-      HIP_TRY(launch_fb_backend(fbk, n_pairs, stream));
-      HIP_TRY(hipEventRecord(e1, stream));
-      c->spans.push_back({e0, e1, 2});
-      prev = nb;
-    }
-  }
+  if (fb_done) HIP_TRY(hipStreamWaitEvent(stream, fb_done, 0));
   HIP_TRY(launch_finalize(c->state.as<PairState>(), advanced, channels, n_pairs,
                           reinterpret_cast<ResultRecord*>(d_results), stream));
   HIP_TRY(hipEventRecord(c->batch_end, stream));
