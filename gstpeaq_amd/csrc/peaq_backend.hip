@@ -310,8 +310,10 @@ struct BackendShared {
   int gate[2];
 };
 
+// 3 waves per SIMD requested: the back end runs BESIDE the front end of the next chunk (which
+// holds 3 x 168 VGPRs per SIMD); with the default budget (256) it could never be co-scheduled
 template <int NB, bool ADV>
-__global__ __launch_bounds__(128) void backend_kernel(BackendArgs a) {
+__global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
   __shared__ BackendShared sh;
   constexpr int SLOTS = 2;
   const int lane = threadIdx.x & 63;

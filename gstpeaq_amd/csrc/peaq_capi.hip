@@ -160,7 +160,12 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
   }
   HIP_TRY(hipEventCreate(&c->batch_begin));
   HIP_TRY(hipEventCreate(&c->batch_end));
-  HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+  {
+    // the back end is the latency-bound consumer of the pipeline: give its stream priority
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
+  }
   HIP_TRY(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
   *out = c;
   return PEAQ_OK;

@@ -23,9 +23,11 @@
 //              totalsnr energies           gstpeaq.c:913-918
 //   ref wave : data-boundary detector      gstpeaq.c:1081-1099 (before the FFT)
 //
-// LDS per wave ("unit"), 18496 B: the 17 KiB FFT exchange buffer is reused for
-// the power spectrum P[0..1023], the weighted spectrum Pw[0..775] and 4 KiB of
-// scratch.  All LDS traffic before the barrier is wave-private.
+// LDS per wave ("unit"), 10304 B: the 8.5 KiB FFT exchange buffer (real and
+// imaginary parts go through it one after the other) is reused for the weighted
+// spectrum Pw[0..775] and 4 KiB of scratch; the unweighted spectrum never leaves the
+// registers (the bandwidth MOVs are found with two wave reductions).  That is
+// what lets six workgroups = three waves per SIMD share a CU.
 #include <hip/hip_runtime.h>
 
 #include "peaq_device.h"
@@ -34,10 +36,12 @@
 
 namespace peaq {
 
-constexpr int kUnitDoubles = 2312;            // 18496 B per wave
-constexpr int kOffP = 0;                      // P[1024]
-constexpr int kOffPw = 1024;                  // Pw[776]
-constexpr int kOffScratch = 1800;             // 512 doubles
+// LDS per wave ("unit"): 1288 doubles = 10304 B.  During the FFT the first 1088 doubles are the
+// exchange buffer (one real component of the 1024 complex points at a time, padded); afterwards
+// Pw[0..775] (weighted power spectrum) followed by 512 doubles of scratch.
+constexpr int kUnitDoubles = 1288;
+constexpr int kOffPw = 0;                     // Pw[776]
+constexpr int kOffScratch = 776;              // 512 doubles
 constexpr int kPwLen = 776;
 
 // W_32^q = exp(-2 pi i q / 32), q = 0..15
@@ -54,31 +58,38 @@ __device__ constexpr double kW32im[16] = {-0., -0.19509032201612826785, -0.38268
 
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }   // complex index -> padded slot
 
-__device__ __forceinline__ cplx lds_ldc(const double* base, int idx) {
-  const double2 v = *reinterpret_cast<const double2*>(base + 2 * pad16(idx));
-  return {v.x, v.y};
-}
-__device__ __forceinline__ void lds_stc(double* base, int idx, cplx v) {
-  *reinterpret_cast<double2*>(base + 2 * pad16(idx)) = make_double2(v.re, v.im);
+// One exchange step of the Stockham FFT through the wave's 8.5 KiB buffer: all 16 points
+// go out at wr(r) and come back from rd(r), first the real then the imaginary parts.
+template <typename WR, typename RD>
+__device__ __forceinline__ void exchange16(cplx (&z)[16], double* buf, WR wr, RD rd) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) buf[pad16(wr(r))] = z[r].re;
+  wave_lds_fence();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r].re = buf[pad16(rd(r))];
+  wave_lds_fence();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) buf[pad16(wr(r))] = z[r].im;
+  wave_lds_fence();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r].im = buf[pad16(rd(r))];
+  wave_lds_fence();
 }
 
 // ---------------------------------------------------------------------------
 // 2048-point real DFT of one frame held as z[r] = x[2n] + i x[2n+1], n = lane + 64 r.
-// On return P/Pw of the unit hold the (weighted) power spectrum.
+// On return p[q] is the power spectrum at bin lane + 64 q (registers) and Pw of the unit
+// holds the weighted power spectrum of bins 0..775.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double* unit, int lane,
+__device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double (&p)[16], double* unit, int lane,
                                                      const CommonTables* __restrict__ ct,
                                                      double level_factor) {
-  // pass 1: radix 16, sub-transform size 1 -> out[16 lane + r]
+  // pass 1: radix 16, sub-transform size 1 -> out[16 lane + r]; pass 2 reads in[lane + 64 r]
   dft16(z);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) lds_stc(unit, 16 * lane + r, z[r]);
-  wave_lds_fence();
+  exchange16(z, unit, [&](int r) { return 16 * lane + r; }, [&](int r) { return lane + 64 * r; });
   // pass 2: radix 16, sub-transform size 16
   {
     const int k = lane & 15;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = lds_ldc(unit, lane + 64 * r);
     {
       // twiddles W_256^(r k) = W_2048^(8 r k), r = 1..15: four table reads (r = 1, 2, 4, 8),
       // the rest as products -- 4 instead of 15 trips to L2 per lane
@@ -98,16 +109,11 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double* unit
     }
     dft16(z);
     const int j = (lane - k) * 16 + k;
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lds_stc(unit, j + 16 * r, z[r]);
+    // out[j + 16 r]; pass 3 (radix 4, sub-transform size 256) reads in[lane + 64 m + 256 r'] into
+    // slot m + 4 r', i.e. slot s reads lane + 64 (s & 3) + 256 (s >> 2)
+    exchange16(z, unit, [&](int r) { return j + 16 * r; },
+               [&](int s) { return lane + 64 * (s & 3) + 256 * (s >> 2); });
   }
-  wave_lds_fence();
-  // pass 3: radix 4, sub-transform size 256; four butterflies per lane
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) z[m + 4 * r] = lds_ldc(unit, lane + 64 * m + 256 * r);
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int i = lane + 64 * m;
@@ -119,14 +125,19 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double* unit
     z[m + 12] = cmul(z[m + 12], w3);
     dft4(z[m], z[m + 4], z[m + 8], z[m + 12]);
   }
-  // z[q] = Z[lane + 64 q].  Publish, then fetch the mirror bins Z[1024 - k].
-  wave_lds_fence();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) lds_stc(unit, lane + 64 * q, z[q]);
-  wave_lds_fence();
+  // z[q] = Z[lane + 64 q].  The mirror bins Z[1024 - k] come back through the buffer as well.
   cplx zm[16];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) zm[q] = lds_ldc(unit, (1024 - (lane + 64 * q)) & 1023);
+  for (int q = 0; q < 16; ++q) unit[pad16(lane + 64 * q)] = z[q].re;
+  wave_lds_fence();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) zm[q].re = unit[pad16((1024 - (lane + 64 * q)) & 1023)];
+  wave_lds_fence();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) unit[pad16(lane + 64 * q)] = z[q].im;
+  wave_lds_fence();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) zm[q].im = unit[pad16((1024 - (lane + 64 * q)) & 1023)];
   wave_lds_fence();
   // even/odd split: X[k] = E[k] + W_2048^k O[k], k = lane + 64 q:
   // W_2048^k = W_2048^lane * W_32^q, the second factor is a compile-time constant
@@ -138,9 +149,8 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double* unit
     const cplx o = {0.5 * (z[q].im + zm[q].im), -0.5 * (z[q].re - zm[q].re)};
     const cplx wq = {kW32re[q], kW32im[q]};
     const cplx x = cadd(e, cmul(q == 0 ? wl : cmul(wl, wq), o));
-    const double p = (x.re * x.re + x.im * x.im) * level_factor;     // fftearmodel.c:464-466
-    unit[kOffP + k] = p;
-    if (k < kPwLen) unit[kOffPw + k] = p * ct->ear_w2[k];             // fftearmodel.c:470-472
+    p[q] = (x.re * x.re + x.im * x.im) * level_factor;               // fftearmodel.c:464-466
+    if (k < kPwLen) unit[kOffPw + k] = p[q] * ct->ear_w2[k];          // fftearmodel.c:470-472
   }
   wave_lds_fence();
 }
@@ -221,7 +231,7 @@ struct FrameSrc {
 };
 
 template <int NB>
-__global__ __launch_bounds__(128) void frontend_kernel(FrontendArgs a) {
+__global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63;
   const int sig = threadIdx.x >> 6;                  // 0 = reference wave, 1 = test wave
@@ -302,7 +312,44 @@ __global__ __launch_bounds__(128) void frontend_kernel(FrontendArgs a) {
     }
   }
 
-  frame_power_spectrum(z, unit, lane, ct, a.level_factor);
+  double pspec[16];                                  // unweighted power spectrum, bin lane + 64 q
+  frame_power_spectrum(z, pspec, unit, lane, ct, a.level_factor);
+
+  // ---- bandwidths (movs.c:776-809) on the unweighted spectra, straight from the registers.
+  // Both waves are in lock step here, the two barriers are cheap.
+  int bw_ref = 0, bw_test = 0;
+  {
+    double* xch = lds + 2 * kUnitDoubles;            // [2] exchanged scalars
+    double thr = 0.;                                 // powers are >= 0
+    if (sig == 1) {
+      // zero threshold = max over bins 921..1023 of the test spectrum
+      if (lane >= 25) thr = pspec[14];               // bin 896 + lane
+      thr = fmax(thr, pspec[15]);                    // bin 960 + lane
+      thr = wave_max(thr);
+      if (lane == 0) xch[0] = thr;
+    }
+    __syncthreads();
+    thr = xch[0];
+    if (sig == 0) {
+#pragma unroll
+      for (int q = 0; q < 15; ++q) {                 // ascending bins: the last hit is the largest
+        const int k = lane + 64 * q;
+        if (k < 921 && pspec[q] > 10. * thr) bw_ref = k + 1;
+      }
+      bw_ref = wave_max_i(bw_ref);
+      if (lane == 0) xch[1] = (double)bw_ref;
+    }
+    __syncthreads();
+    bw_ref = (int)xch[1];
+    if (sig == 1 && bw_ref > 346) {
+#pragma unroll
+      for (int q = 0; q < 15; ++q) {
+        const int k = lane + 64 * q;
+        if (k < bw_ref && pspec[q] >= 3.16227766016838 * thr) bw_test = k + 1;
+      }
+      bw_test = wave_max_i(bw_test);
+    }
+  }
 
   // ---- critical bands, internal noise, spreading ------------------------------------
   // lane owns bands 2*lane and 2*lane+1
@@ -383,10 +430,8 @@ __global__ __launch_bounds__(128) void frontend_kernel(FrontendArgs a) {
   }
 
   __syncthreads();                                   // both spectra are in LDS
-  const double* p_ref = lds + kOffP;
-  double* p_test = lds + kUnitDoubles + kOffP;
   const double* pw_ref = lds + kOffPw;
-  const double* pw_test = lds + kUnitDoubles + kOffPw;
+  double* pw_test = lds + kUnitDoubles + kOffPw;
   double* dlog = lds + kOffScratch;                          // [512] shared: ln(Pw_test / Pw_ref)
   double* cbuf = lds + kUnitDoubles + kOffScratch;           // [256] shared: correlation by lag
 
@@ -421,33 +466,19 @@ __global__ __launch_bounds__(128) void frontend_kernel(FrontendArgs a) {
   __syncthreads();
 
   if (sig == 1) {
-    // ---- bandwidths (movs.c:776-809), unweighted spectrum ------------------------
-    double thr = 0.;                                 // powers are >= 0
-    for (int k = 921 + lane; k < 1024; k += 64) thr = fmax(thr, p_test[k]);
-    thr = wave_max(thr);
-    int bw_ref = 0;
-    for (int k = lane; k < 921; k += 64)
-      if (p_ref[k] > 10. * thr) bw_ref = k + 1;     // ascending k: the last hit is the largest
-    bw_ref = wave_max_i(bw_ref);
-    int bw_test = 0;
-    if (bw_ref > 346) {
-      for (int k = lane; k < bw_ref; k += 64)
-        if (p_test[k] >= 3.16227766016838 * thr) bw_test = k + 1;
-      bw_test = wave_max_i(bw_test);
-    }
-    // ---- noise spectrum for the NMR MOVs (movs.c:992-996): one bin per lane and step,
-    // overwriting this unit's (now dead) unweighted spectrum; then the band grouping ---------
+    // ---- noise spectrum for the NMR MOVs (movs.c:992-996): one bin per lane and step, in place
+    // over this unit's weighted spectrum (nobody reads it any more); then the band grouping ------
     wave_lds_fence();
     for (int k = lane; k < kPwLen; k += 64) {
       const double r = pw_ref[k], t = pw_test[k];
-      p_test[k] = r - 2 * sqrt(r * t) + t;
+      pw_test[k] = r - 2 * sqrt(r * t) + t;
     }
     wave_lds_fence();
     double nib[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int b = b0 + s;
-      nib[s] = b < NB ? group_band(bt, b, [&](int k) { return p_test[k]; }) : 0.;
+      nib[s] = b < NB ? group_band(bt, b, [&](int k) { return pw_test[k]; }) : 0.;
     }
     if (b0 < kBandStride) *reinterpret_cast<double2*>(rec + kRecNoise + b0) = make_double2(nib[0], nib[1]);
     // ---- totalsnr energies over the hop (gstpeaq.c:913-918; float products) --------
@@ -562,7 +593,7 @@ __global__ __launch_bounds__(128) void frontend_kernel(FrontendArgs a) {
 hipError_t launch_frontend(int bands, const FrontendArgs& a, unsigned n_pairs, hipStream_t stream) {
   const unsigned grid = n_pairs * a.frames_per_launch * a.channels;
   if (grid == 0) return hipSuccess;
-  const size_t lds = 2 * kUnitDoubles * sizeof(double);
+  const size_t lds = (2 * kUnitDoubles + 2) * sizeof(double);
   if (bands == 109)
     hipLaunchKernelGGL(frontend_kernel<109>, dim3(grid), dim3(128), lds, stream, a);
   else if (bands == 55)
