@@ -354,8 +354,10 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
   // ---- critical bands, internal noise, spreading ------------------------------------
   // lane owns bands 2*lane and 2*lane+1
   const double* pw = unit + kOffPw;
-  double* e2up = scratch;                            // [224] upward-spreading accumulators
-  for (int i = lane; i < 224; i += 64) e2up[i] = 0.;
+  // upward-spreading accumulators, split by target parity: up[par][idx] = E2up[2 idx + par].
+  // All lanes of one atomic hit the same parity at consecutive idx (8-byte stride): no bank conflicts.
+  double* e2up = scratch;                            // [2][128]
+  for (int i = lane; i < 256; i += 64) e2up[i] = 0.;
   double ene[2], ae[2];
   const int b0 = 2 * lane;
 #pragma unroll
@@ -385,8 +387,9 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     for (int s = 1; s < NB; ++s) {
       r0 *= ae[0];
       r1 *= ae[1];
-      atomicAdd(&e2up[b0 + s], r0);
-      atomicAdd(&e2up[b0 + 1 + s], r1);
+      // targets 2 lane + s and 2 lane + 1 + s
+      atomicAdd(&e2up[128 * (s & 1) + lane + (s >> 1)], r0);
+      atomicAdd(&e2up[128 * ((s + 1) & 1) + lane + ((s + 1) >> 1)], r1);
     }
   }
   // downward spreading, Kabal (28): E2[i-1] = aLe E2[i] + Ene[i-1]  (suffix scan)
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int b = b0 + s;
-    const double e2 = (s ? dn1 : dn0) + e2up[b < NB ? b : 0];
+    const double e2 = (s ? dn1 : dn0) + e2up[128 * s + lane];   // band 2 lane + s
     // (25): E = E2^(1/0.4) / normalisation, and E^0.3 for the modulation patterns (modpatt.c:235),
     // both from square roots: x^2.5 = x^2 sqrt(x), (x^2.5)^0.3 = x^0.75 = sqrt(x) sqrt(sqrt(x))
     const int bb = b < NB ? b : 0;
