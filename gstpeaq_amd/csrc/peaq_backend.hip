@@ -400,13 +400,17 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
       }
     }
 
-    double v_val[kMaxAcc], v_w[kMaxAcc];
-    int mask = 0;
-#pragma unroll
-    for (int i = 0; i < kMaxAcc; ++i) {
-      v_val[i] = 0.;
-      v_w[i] = 1.;
-    }
+    // lane i owns accumulator i: every MOV value of the frame is routed to its owner as soon as
+    // it exists (two selects) instead of being kept in a per-lane table
+    double my_v = 0., my_w = 1.;
+    bool my_hit = false;
+    auto route = [&](int idx, double v, double w) {
+      if (lane == idx) {
+        my_v = v;
+        my_w = w;
+        my_hit = true;
+      }
+    };
 
     if (!ADV) {
       // ---- pattern processing (gstpeaq.c:834-845) ------------------------------------
@@ -451,23 +455,20 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
         mod_difference<NB, SLOTS>(bl, bt, 100., mr, mt, mdr[1], d1, d2, wt);
         d1 *= 100. / NB;
         d2 *= 100. / NB;
-        v_val[MB_AVGMOD1] = d1; v_w[MB_AVGMOD1] = wt;
-        v_val[MB_AVGMOD2] = d2; v_w[MB_AVGMOD2] = wt;
-        v_val[MB_WINMOD] = d1;
-        mask |= (1 << MB_AVGMOD1) | (1 << MB_AVGMOD2) | (1 << MB_WINMOD);
+        route(MB_AVGMOD1, d1, wt);
+        route(MB_AVGMOD2, d2, wt);
+        route(MB_WINMOD, d1, 1.);
       }
       // ---- noise loudness (gstpeaq.c:880-886; unsigned compare with UINT_MAX sentinel)
       if (frame >= 24 && frame - 3 >= loud_reached) {
-        v_val[MB_NOISELOUD] = noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 0.5, 0., mr, mt, ad_ref, ad_test);
-        mask |= 1 << MB_NOISELOUD;
+        route(MB_NOISELOUD, noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 0.5, 0., mr, mt, ad_ref, ad_test), 1.);
       }
       // ---- bandwidth (movs.c:797-807) ------------------------------------------------------
       {
         const double bw_ref = rec[kRecBwRef];
         if (bw_ref > 346.) {
-          v_val[MB_BW_REF] = bw_ref;
-          v_val[MB_BW_TEST] = rec[kRecBwTest];
-          mask |= (1 << MB_BW_REF) | (1 << MB_BW_TEST);
+          route(MB_BW_REF, bw_ref, 1.);
+          route(MB_BW_TEST, rec[kRecBwTest], 1.);
         }
       }
     }
@@ -486,18 +487,15 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
       nsum = wave_sum(nsum) / NB;
       nmax = wave_max(nmax);
       if (!ADV) {
-        v_val[MB_NMR] = nsum;                                       // MODE_AVG_LOG
-        v_val[MB_RELDIST] = nmax > 1.41253754462275 ? 1. : 0.;
-        mask |= (1 << MB_NMR) | (1 << MB_RELDIST);
+        route(MB_NMR, nsum, 1.);                                    // MODE_AVG_LOG
+        route(MB_RELDIST, nmax > 1.41253754462275 ? 1. : 0., 1.);
       } else {
-        v_val[MA_SEGNMR] = 10. * log10(nsum);                       // MODE_AVG
-        mask |= 1 << MA_SEGNMR;
+        route(MA_SEGNMR, 10. * log10(nsum), 1.);                    // MODE_AVG
       }
     }
     // ---- error harmonic structure (movs.c:1374-1381,1442) ------------------------------
     if (ehs_valid) {
-      v_val[ADV ? MA_EHS : MB_EHS] = 1000. * rec[kRecEhs];
-      mask |= 1 << (ADV ? MA_EHS : MB_EHS);
+      route(ADV ? MA_EHS : MB_EHS, 1000. * rec[kRecEhs], 1.);
     }
     // ---- detection probability, binaural part (movs.c:1263-1275) --------------------------
     if (!ADV && chan == 0) {
@@ -518,12 +516,8 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
       }
       const double p_bin = 1. - wave_prod(pprod);
       qsum = wave_sum(qsum);
-      if (p_bin > 0.5) {
-        v_val[MB_ADB] = qsum;
-        mask |= 1 << MB_ADB;
-      }
-      v_val[MB_MFPD] = p_bin;
-      mask |= 1 << MB_MFPD;
+      if (p_bin > 0.5) route(MB_ADB, qsum, 1.);
+      route(MB_MFPD, p_bin, 1.);
     }
     // ---- totalsnr (gstpeaq.c:913-918) --------------------------------------------------------
     if (chan == 0) {
@@ -531,17 +525,7 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
       noise_e += rec0[kRecNoiseE] + (channels == 2 ? rec0[kRecDoubles + kRecNoiseE] : 0.);
     }
     // ---- accumulate: lane i owns accumulator i --------------------------------------------------
-    {
-      double my_v = 0., my_w = 1.;
-#pragma unroll
-      for (int i = 0; i < kMaxAcc; ++i) {
-        if (lane == i) {
-          my_v = v_val[i];
-          my_w = v_w[i];
-        }
-      }
-      if (lane < kMaxAcc && ((mask >> lane) & 1)) acc.add(my_v, my_w);
-    }
+    if (my_hit) acc.add(my_v, my_w);
     if (!ADV) __syncthreads();                       // sh.pc/qc/gate are rewritten next frame
   }
 

@@ -93,7 +93,8 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double (&p)[
     {
       // twiddles W_256^(r k) = W_2048^(8 r k), r = 1..15: four table reads (r = 1, 2, 4, 8),
       // the rest as products -- 4 instead of 15 trips to L2 per lane
-      cplx w[16];
+      // (applied as soon as they exist: only w1..w8 stay live, the register budget is 168)
+      cplx w[9];
       w[1] = {ct->tw_re[8 * k], ct->tw_im[8 * k]};
       w[2] = {ct->tw_re[16 * k], ct->tw_im[16 * k]};
       w[4] = {ct->tw_re[32 * k], ct->tw_im[32 * k]};
@@ -103,9 +104,11 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double (&p)[
       w[6] = cmul(w[4], w[2]);
       w[7] = cmul(w[4], w[3]);
 #pragma unroll
-      for (int r = 1; r < 8; ++r) w[8 + r] = cmul(w[8], w[r]);
-#pragma unroll
-      for (int r = 1; r < 16; ++r) z[r] = cmul(z[r], w[r]);
+      for (int r = 1; r < 8; ++r) {
+        z[8 + r] = cmul(z[8 + r], cmul(w[8], w[r]));
+        z[r] = cmul(z[r], w[r]);
+      }
+      z[8] = cmul(z[8], w[8]);
     }
     dft16(z);
     const int j = (lane - k) * 16 + k;
@@ -125,28 +128,21 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double (&p)[
     z[m + 12] = cmul(z[m + 12], w3);
     dft4(z[m], z[m + 4], z[m + 8], z[m + 12]);
   }
-  // z[q] = Z[lane + 64 q].  The mirror bins Z[1024 - k] come back through the buffer as well.
-  cplx zm[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) unit[pad16(lane + 64 * q)] = z[q].re;
-  wave_lds_fence();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) zm[q].re = unit[pad16((1024 - (lane + 64 * q)) & 1023)];
-  wave_lds_fence();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) unit[pad16(lane + 64 * q)] = z[q].im;
-  wave_lds_fence();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) zm[q].im = unit[pad16((1024 - (lane + 64 * q)) & 1023)];
-  wave_lds_fence();
-  // even/odd split: X[k] = E[k] + W_2048^k O[k], k = lane + 64 q:
-  // W_2048^k = W_2048^lane * W_32^q, the second factor is a compile-time constant
+  // z[q] = Z[lane + 64 q].  The even/odd split needs the mirror bin Z[1024 - k]: it lives in
+  // lane 64 - lane, slot 15 - q (lane 0: own slot 16 - q, and Z[1024] = Z[0]) -- a lane
+  // permutation, done bin by bin through the crossbar so that no extra registers pile up.
+  // X[k] = E[k] + W_2048^k O[k], k = lane + 64 q; W_2048^k = W_2048^lane * W_32^q, the second
+  // factor is a compile-time constant.
+  wave_lds_fence();                                  // the exchange buffer is about to become Pw
   const cplx wl = {ct->tw_re[lane], ct->tw_im[lane]};
+  const int partner = (64 - lane) & 63;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int k = lane + 64 * q;
-    const cplx e = {0.5 * (z[q].re + zm[q].re), 0.5 * (z[q].im - zm[q].im)};
-    const cplx o = {0.5 * (z[q].im + zm[q].im), -0.5 * (z[q].re - zm[q].re)};
+    cplx zm = {__shfl(z[15 - q].re, partner, 64), __shfl(z[15 - q].im, partner, 64)};
+    if (lane == 0) zm = z[(16 - q) & 15];
+    const cplx e = {0.5 * (z[q].re + zm.re), 0.5 * (z[q].im - zm.im)};
+    const cplx o = {0.5 * (z[q].im + zm.im), -0.5 * (z[q].re - zm.re)};
     const cplx wq = {kW32re[q], kW32im[q]};
     const cplx x = cadd(e, cmul(q == 0 ? wl : cmul(wl, wq), o));
     p[q] = (x.re * x.re + x.im * x.im) * level_factor;               // fftearmodel.c:464-466
