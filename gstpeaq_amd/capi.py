@@ -31,6 +31,11 @@ class _Timing(C.Structure):
 _LIB = None
 
 
+class _BrokerStats(C.Structure):
+    _fields_ = [("ticks", C.c_uint64), ("launches", C.c_uint64), ("frames", C.c_uint64),
+                ("max_active", C.c_uint32), ("worker_failed", C.c_uint32)]
+
+
 def library_path():
     return PKG / "libpeaq_amd.so"
 
@@ -80,6 +85,19 @@ def load_library():
     L.peaq_debug_frontend.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp, vp, C.c_uint32, C.c_uint32,
                                       C.c_int, dp]
     L.peaq_debug_filterbank.argtypes = [vp, C.c_int, C.c_double, vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, dp]
+    ip = C.POINTER(C.c_int)
+    L.peaq_broker_create.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.POINTER(vp)]
+    L.peaq_broker_destroy.argtypes = [vp]
+    L.peaq_broker_destroy.restype = None
+    L.peaq_broker_open.argtypes = [vp, ip]
+    L.peaq_broker_close.argtypes = [vp, C.c_int]
+    L.peaq_broker_push.argtypes = [vp, C.c_int, C.c_int, fp, C.c_size_t]
+    L.peaq_broker_flush.argtypes = [vp, C.c_int]
+    L.peaq_broker_tick.argtypes = [vp, C.POINTER(C.c_uint)]
+    L.peaq_broker_results.argtypes = [vp, C.c_int, dp]
+    L.peaq_broker_start.argtypes = [vp, C.c_uint]
+    L.peaq_broker_stop.argtypes = [vp]
+    L.peaq_broker_stats.argtypes = [vp, C.POINTER(_BrokerStats)]
     _LIB = L
     return L
 
@@ -153,6 +171,65 @@ class Session:
     def close(self):
         if self.h:
             self.L.peaq_session_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Broker:
+    """Many live sessions (one per hosted `peaq` element), one batched launch per tick."""
+
+    def __init__(self, ctx, channels, max_sessions, playback_level=92.0):
+        self.ctx, self.channels = ctx, channels
+        self.L = ctx.L
+        self.h = C.c_void_p()
+        _check(self.L.peaq_broker_create(ctx.h, int(channels), float(playback_level), int(max_sessions),
+                                         C.byref(self.h)))
+
+    def open(self):
+        sid = C.c_int(-1)
+        _check(self.L.peaq_broker_open(self.h, C.byref(sid)))
+        return sid.value
+
+    def close_session(self, sid):
+        _check(self.L.peaq_broker_close(self.h, int(sid)))
+
+    def push(self, sid, pad, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        _check(self.L.peaq_broker_push(self.h, int(sid), int(pad), x.ctypes.data_as(C.POINTER(C.c_float)),
+                                       x.size // self.channels))
+
+    def flush(self, sid):
+        _check(self.L.peaq_broker_flush(self.h, int(sid)))
+
+    def tick(self):
+        n = C.c_uint(0)
+        _check(self.L.peaq_broker_tick(self.h, C.byref(n)))
+        return n.value
+
+    def results(self, sid):
+        out = np.zeros(RESULT_DOUBLES)
+        _check(self.L.peaq_broker_results(self.h, int(sid), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return _result_dict(out, False)
+
+    def start(self, period_us=2000):
+        _check(self.L.peaq_broker_start(self.h, int(period_us)))
+
+    def stop(self):
+        _check(self.L.peaq_broker_stop(self.h))
+
+    def stats(self):
+        st = _BrokerStats()
+        _check(self.L.peaq_broker_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in _BrokerStats._fields_}
+
+    def close(self):
+        if self.h:
+            self.L.peaq_broker_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

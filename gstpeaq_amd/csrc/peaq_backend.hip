@@ -322,13 +322,20 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
   const unsigned pair = blockIdx.x;
   const BandTables* __restrict__ bt = a.bands;
   const BandLane<NB, SLOTS> bl{lane};
-  PairState* __restrict__ ps = a.state + pair;
+  PairState* __restrict__ ps = a.state + (a.pair_slot ? a.pair_slot[pair] : pair);
   ChannelState* __restrict__ cs = &ps->ch[chan];
 
-  const unsigned n_frames = a.n_frames ? a.n_frames[pair] : a.n_frames_uniform;
-  unsigned f_end = a.frame0 + a.frames_per_launch;
-  if (f_end > n_frames) f_end = n_frames;
-  if (a.frame0 >= f_end) return;
+  unsigned f_begin, f_end;
+  if (a.pair_frame0) {                               // broker launch: this pair's own window
+    f_begin = a.pair_frame0[pair];
+    f_end = f_begin + a.pair_nframes[pair];
+  } else {
+    const unsigned n_frames = a.n_frames ? a.n_frames[pair] : a.n_frames_uniform;
+    f_begin = a.frame0;
+    f_end = a.frame0 + a.frames_per_launch;
+    if (f_end > n_frames) f_end = n_frames;
+  }
+  if (f_begin >= f_end) return;
 
   // ---- recurrent state -> registers -----------------------------------------------
   double sm[2][SLOTS];                               // smeared excitation filters (ref, test)
@@ -355,9 +362,9 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
   unsigned loud_reached = ps->loudness_reached;
   double sig_e = ps->sig_energy, noise_e = ps->noise_energy;
 
-  for (unsigned frame = a.frame0; frame < f_end; ++frame) {
+  for (unsigned frame = f_begin; frame < f_end; ++frame) {
     const double* __restrict__ rec0 =
-        a.records + ((size_t)(pair * a.frames_per_launch + (frame - a.frame0)) * channels) * kRecDoubles;
+        a.records + ((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels) * kRecDoubles;
     const double* __restrict__ rec = rec0 + (size_t)chan * kRecDoubles;
 
     // ---- frame flags over all channels (gstpeaq.c:858-862, movs.c:1374-1381) -----

@@ -10,12 +10,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/peaq_amd.h"
@@ -879,5 +882,356 @@ extern "C" int peaq_session_reset(peaq_session* s) {
   if (s->advanced)
     HIP_TRY(hipMemsetAsync(s->fbstate.p, 0, 2 * s->channels * sizeof(FbSignalState), s->stream));
   HIP_TRY(launch_state_init(s->state.as<PairState>(), s->advanced, 1, s->stream));
+  return PEAQ_OK;
+}
+
+// ---------------------------------------------------------------------------
+// broker: many live sessions, one launch per tick
+// ---------------------------------------------------------------------------
+// A process that hosts many `peaq` elements (BASELINE.json configs[5]: 1024
+// concurrent live pipelines) would otherwise issue one 1-workgroup launch pair
+// per element and buffer.  The broker keeps the FIFOs of all its sessions on
+// the host and, on every tick, gathers whatever frames became ready in ANY
+// session into ONE front-end and ONE back-end launch: workgroup (pair p, frame
+// fl) of that grid is frame pair_frame0[p] + fl of session pair_slot[p].  The
+// recurrent state of a session stays in its PairState slot in HBM between
+// ticks, so the result of a session is the same whether its frames were run
+// alone, in a batch, or interleaved with other sessions' frames.
+// Basic model only (the filter-bank path of the advanced model has no per-pair
+// block windows yet); the framing per session is that of do_processing /
+// do_flush (gstpeaq.c:596-611, 716-745).
+namespace {
+constexpr unsigned kBrokerMaxFrames = 8;     // frames one session contributes to one tick
+constexpr size_t kBrokerStageSamples = (size_t)(kBrokerMaxFrames - 1) * kHop + kFrame;
+
+struct BrokerSlot {
+  std::mutex mu;
+  bool open = false;
+  bool flush_requested = false;
+  PadFifo pad[2];
+  uint64_t fft_pos[2] = {0, 0};
+  uint32_t frames_done = 0;
+};
+}  // namespace
+
+struct peaq_broker {
+  peaq_ctx* ctx = nullptr;
+  int channels = 1;
+  double level_db = 92.;
+  int max_sessions = 0;
+  std::vector<BrokerSlot*> slots;
+  std::mutex tick_mu;               // one tick at a time; guards everything below
+  hipStream_t stream = nullptr;
+  hipEvent_t staged = nullptr;
+  bool staged_pending = false;
+  float* h_stage[2] = {nullptr, nullptr};   // pinned, [launch pair][kBrokerStageSamples][channels]
+  uint32_t* h_meta = nullptr;               // pinned, 5 rows of max_sessions: n_ref, n_test, frame0, nframes, slot
+  DevBuf d_sig[2], d_meta, records, state, result;
+  std::thread worker;
+  std::atomic<bool> running{false};
+  unsigned period_us = 0;
+  std::string worker_error;
+  uint64_t n_ticks = 0, n_launches = 0, n_frames = 0;
+  uint32_t max_active = 0;
+};
+
+static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
+  peaq_ctx* c = b->ctx;
+  if (n_active_out) *n_active_out = 0;
+  HIP_TRY(hipSetDevice(c->device));
+  if (b->staged_pending) {
+    HIP_TRY(hipEventSynchronize(b->staged));
+    b->staged_pending = false;
+  }
+  const size_t S = (size_t)b->max_sessions;
+  uint32_t* m_nref = b->h_meta;
+  uint32_t* m_ntest = b->h_meta + S;
+  uint32_t* m_f0 = b->h_meta + 2 * S;
+  uint32_t* m_nf = b->h_meta + 3 * S;
+  uint32_t* m_slot = b->h_meta + 4 * S;
+  const size_t stride = kBrokerStageSamples * b->channels;   // floats per launch pair
+  unsigned active = 0, max_nf = 0;
+  uint64_t frames = 0;
+  for (int sid = 0; sid < b->max_sessions; ++sid) {
+    BrokerSlot& sl = *b->slots[sid];
+    std::lock_guard<std::mutex> lock(sl.mu);
+    if (!sl.open) continue;
+    const uint64_t left[2] = {sl.pad[0].total - sl.fft_pos[0], sl.pad[1].total - sl.fft_pos[1]};
+    const uint64_t av = std::min(left[0], left[1]);
+    unsigned nf = 0;
+    uint64_t nv[2] = {0, 0}, adv[2] = {0, 0};
+    if (av >= (uint64_t)kFrame) {                                   // do_processing
+      nf = static_cast<unsigned>(std::min<uint64_t>((av - kFrame) / kHop + 1, kBrokerMaxFrames));
+      nv[0] = nv[1] = (uint64_t)(nf - 1) * kHop + kFrame;
+      adv[0] = adv[1] = (uint64_t)nf * kHop;
+    } else if (sl.flush_requested) {                                // do_flush
+      sl.flush_requested = false;
+      if (left[0] || left[1]) {
+        nf = 1;
+        nv[0] = adv[0] = std::min<uint64_t>(left[0], kFrame);
+        nv[1] = adv[1] = std::min<uint64_t>(left[1], kFrame);
+      }
+    }
+    if (!nf) continue;
+    for (int p = 0; p < 2; ++p) {
+      PadFifo& f = sl.pad[p];
+      if (nv[p])
+        std::memcpy(b->h_stage[p] + active * stride, f.buf.data() + (size_t)(sl.fft_pos[p] - f.base) * b->channels,
+                    (size_t)nv[p] * b->channels * sizeof(float));
+      sl.fft_pos[p] += adv[p];
+      const size_t drop = (size_t)(sl.fft_pos[p] - f.base) * b->channels;
+      f.buf.erase(f.buf.begin(), f.buf.begin() + std::min(drop, f.buf.size()));
+      f.base = sl.fft_pos[p];
+    }
+    m_nref[active] = static_cast<uint32_t>(nv[0]);
+    m_ntest[active] = static_cast<uint32_t>(nv[1]);
+    m_f0[active] = sl.frames_done;
+    m_nf[active] = nf;
+    m_slot[active] = static_cast<uint32_t>(sid);
+    sl.frames_done += nf;
+    frames += nf;
+    max_nf = std::max(max_nf, nf);
+    ++active;
+  }
+  ++b->n_ticks;
+  if (!active) return PEAQ_OK;
+  for (int p = 0; p < 2; ++p)
+    HIP_TRY(hipMemcpyAsync(b->d_sig[p].p, b->h_stage[p], active * stride * sizeof(float), hipMemcpyHostToDevice,
+                           b->stream));
+  HIP_TRY(hipMemcpyAsync(b->d_meta.p, b->h_meta, 5 * S * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+  const uint32_t* d_meta = b->d_meta.as<uint32_t>();
+  FrontendArgs fa{};
+  fa.ref = b->d_sig[0].as<float>();
+  fa.test = b->d_sig[1].as<float>();
+  fa.pair_stride = kBrokerStageSamples;
+  fa.n_ref = d_meta;
+  fa.n_test = d_meta + S;
+  fa.pair_frame0 = d_meta + 2 * S;
+  fa.pair_nframes = d_meta + 3 * S;
+  fa.channels = b->channels;
+  fa.frames_per_launch = max_nf;
+  fa.level_factor = fft_level_factor(b->level_db);
+  fa.common = c->d_common;
+  fa.bands = c->d_bands109;
+  fa.records = b->records.as<double>();
+  HIP_TRY(launch_frontend(109, fa, active, b->stream));
+  BackendArgs ba{};
+  ba.records = fa.records;
+  ba.frames_per_launch = max_nf;
+  ba.channels = b->channels;
+  ba.advanced = 0;
+  ba.bands = fa.bands;
+  ba.state = b->state.as<PairState>();
+  ba.pair_frame0 = fa.pair_frame0;
+  ba.pair_nframes = fa.pair_nframes;
+  ba.pair_slot = d_meta + 4 * S;
+  HIP_TRY(launch_backend(ba, active, b->stream));
+  HIP_TRY(hipEventRecord(b->staged, b->stream));
+  b->staged_pending = true;
+  ++b->n_launches;
+  b->n_frames += frames;
+  b->max_active = std::max(b->max_active, active);
+  if (n_active_out) *n_active_out = active;
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_broker_create(peaq_ctx* c, int channels, double level_db, int max_sessions, peaq_broker** out) {
+  if (!c || !out) return fail(PEAQ_ERR_ARG, "peaq_broker_create: NULL argument");
+  *out = nullptr;
+  if (channels != 1 && channels != 2) return fail(PEAQ_ERR_ARG, "peaq_broker_create: channels must be 1 or 2");
+  if (!(level_db >= 0. && level_db <= 130.))
+    return fail(PEAQ_ERR_ARG, "peaq_broker_create: playback level outside 0..130 dB (gstpeaq.c:275-281)");
+  if (max_sessions < 1 || max_sessions > 65536) return fail(PEAQ_ERR_ARG, "peaq_broker_create: max_sessions 1..65536");
+  HIP_TRY(hipSetDevice(c->device));
+  peaq_broker* b = new (std::nothrow) peaq_broker;
+  if (!b) return fail(PEAQ_ERR_NOMEM, "out of host memory");
+  b->ctx = c;
+  b->channels = channels;
+  b->level_db = level_db;
+  b->max_sessions = max_sessions;
+  b->slots.reserve(max_sessions);
+  for (int i = 0; i < max_sessions; ++i) b->slots.push_back(new BrokerSlot);
+  const size_t S = (size_t)max_sessions;
+  const size_t sig_bytes = S * kBrokerStageSamples * channels * sizeof(float);
+  int rc = [&]() -> int {
+    for (int p = 0; p < 2; ++p) {
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage[p]), sig_bytes, hipHostMallocDefault));
+      HIP_TRY(b->d_sig[p].reserve(sig_bytes));
+    }
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_meta), 5 * S * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(b->d_meta.reserve(5 * S * sizeof(uint32_t)));
+    HIP_TRY(b->records.reserve(S * kBrokerMaxFrames * channels * kRecDoubles * sizeof(double)));
+    HIP_TRY(b->state.reserve(S * sizeof(PairState)));
+    HIP_TRY(b->result.reserve(sizeof(ResultRecord)));
+    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&b->staged, hipEventDisableTiming));
+    HIP_TRY(launch_state_init(b->state.as<PairState>(), 0, max_sessions, b->stream));
+    return PEAQ_OK;
+  }();
+  if (rc != PEAQ_OK) {
+    peaq_broker_destroy(b);
+    return rc;
+  }
+  *out = b;
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_broker_stop(peaq_broker* b) {
+  if (!b) return fail(PEAQ_ERR_ARG, "peaq_broker_stop: broker is NULL");
+  if (b->running.exchange(false) && b->worker.joinable()) b->worker.join();
+  return PEAQ_OK;
+}
+
+extern "C" void peaq_broker_destroy(peaq_broker* b) {
+  if (!b) return;
+  (void)peaq_broker_stop(b);
+  (void)hipSetDevice(b->ctx->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  for (int p = 0; p < 2; ++p) {
+    if (b->h_stage[p]) (void)hipHostFree(b->h_stage[p]);
+    b->d_sig[p].release();
+  }
+  if (b->h_meta) (void)hipHostFree(b->h_meta);
+  b->d_meta.release();
+  b->records.release();
+  b->state.release();
+  b->result.release();
+  if (b->staged) (void)hipEventDestroy(b->staged);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  for (BrokerSlot* s : b->slots) delete s;
+  delete b;
+}
+
+extern "C" int peaq_broker_open(peaq_broker* b, int* session_id) {
+  if (!b || !session_id) return fail(PEAQ_ERR_ARG, "peaq_broker_open: NULL argument");
+  std::lock_guard<std::mutex> tick(b->tick_mu);
+  for (int sid = 0; sid < b->max_sessions; ++sid) {
+    BrokerSlot& sl = *b->slots[sid];
+    std::lock_guard<std::mutex> lock(sl.mu);
+    if (sl.open) continue;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(launch_state_init(b->state.as<PairState>() + sid, 0, 1, b->stream));
+    sl.open = true;
+    sl.flush_requested = false;
+    sl.pad[0] = PadFifo();
+    sl.pad[1] = PadFifo();
+    sl.fft_pos[0] = sl.fft_pos[1] = 0;
+    sl.frames_done = 0;
+    *session_id = sid;
+    return PEAQ_OK;
+  }
+  return fail(PEAQ_ERR_STATE, "peaq_broker_open: all session slots are in use");
+}
+
+static BrokerSlot* broker_slot(peaq_broker* b, int sid) {
+  if (!b || sid < 0 || sid >= b->max_sessions) return nullptr;
+  return b->slots[sid];
+}
+
+extern "C" int peaq_broker_close(peaq_broker* b, int session_id) {
+  BrokerSlot* sl = broker_slot(b, session_id);
+  if (!sl) return fail(PEAQ_ERR_ARG, "peaq_broker_close: bad broker or session id");
+  std::lock_guard<std::mutex> tick(b->tick_mu);
+  std::lock_guard<std::mutex> lock(sl->mu);
+  if (!sl->open) return fail(PEAQ_ERR_STATE, "peaq_broker_close: session is not open");
+  sl->open = false;
+  sl->pad[0] = PadFifo();
+  sl->pad[1] = PadFifo();
+  return PEAQ_OK;
+}
+
+// pad_chain (gstpeaq.c:613-640): only queues; the device work happens on the next tick
+extern "C" int peaq_broker_push(peaq_broker* b, int session_id, int pad, const float* data, size_t n) {
+  BrokerSlot* sl = broker_slot(b, session_id);
+  if (!sl) return fail(PEAQ_ERR_ARG, "peaq_broker_push: bad broker or session id");
+  if (pad != 0 && pad != 1) return fail(PEAQ_ERR_ARG, "peaq_broker_push: pad must be 0 (ref) or 1 (test)");
+  if (n == 0) return PEAQ_OK;
+  if (!data) return fail(PEAQ_ERR_ARG, "peaq_broker_push: data is NULL");
+  std::lock_guard<std::mutex> lock(sl->mu);
+  if (!sl->open) return fail(PEAQ_ERR_STATE, "peaq_broker_push: session is not open");
+  PadFifo& f = sl->pad[pad];
+  try {
+    f.buf.insert(f.buf.end(), data, data + n * b->channels);
+  } catch (const std::bad_alloc&) {
+    return fail(PEAQ_ERR_NOMEM, "out of host memory");
+  }
+  f.total += n;
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_broker_flush(peaq_broker* b, int session_id) {
+  BrokerSlot* sl = broker_slot(b, session_id);
+  if (!sl) return fail(PEAQ_ERR_ARG, "peaq_broker_flush: bad broker or session id");
+  std::lock_guard<std::mutex> lock(sl->mu);
+  if (!sl->open) return fail(PEAQ_ERR_STATE, "peaq_broker_flush: session is not open");
+  sl->flush_requested = true;
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_broker_tick(peaq_broker* b, unsigned* n_active) {
+  if (!b) return fail(PEAQ_ERR_ARG, "peaq_broker_tick: broker is NULL");
+  std::lock_guard<std::mutex> tick(b->tick_mu);
+  return broker_tick_locked(b, n_active);
+}
+
+// true while the session has whole frames (or a requested flush) not yet launched
+static bool broker_slot_busy(BrokerSlot* sl) {
+  std::lock_guard<std::mutex> lock(sl->mu);
+  const uint64_t av = std::min(sl->pad[0].total - sl->fft_pos[0], sl->pad[1].total - sl->fft_pos[1]);
+  return av >= (uint64_t)kFrame || sl->flush_requested;
+}
+
+extern "C" int peaq_broker_results(peaq_broker* b, int session_id, peaq_result* out) {
+  BrokerSlot* sl = broker_slot(b, session_id);
+  if (!sl || !out) return fail(PEAQ_ERR_ARG, "peaq_broker_results: bad broker, session id or out");
+  std::lock_guard<std::mutex> tick(b->tick_mu);
+  {
+    std::lock_guard<std::mutex> lock(sl->mu);
+    if (!sl->open) return fail(PEAQ_ERR_STATE, "peaq_broker_results: session is not open");
+  }
+  while (broker_slot_busy(sl)) {
+    const int rc = broker_tick_locked(b, nullptr);
+    if (rc != PEAQ_OK) return rc;
+  }
+  HIP_TRY(hipSetDevice(b->ctx->device));
+  HIP_TRY(launch_finalize(b->state.as<PairState>() + session_id, 0, b->channels, 1, b->result.as<ResultRecord>(),
+                          b->stream));
+  HIP_TRY(hipMemcpyAsync(out, b->result.p, sizeof(peaq_result), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_broker_start(peaq_broker* b, unsigned period_us) {
+  if (!b) return fail(PEAQ_ERR_ARG, "peaq_broker_start: broker is NULL");
+  if (b->running.exchange(true)) return fail(PEAQ_ERR_STATE, "peaq_broker_start: already running");
+  b->period_us = period_us ? period_us : 2000;
+  b->worker = std::thread([b]() {
+    // fixed cadence: whatever arrived during one period shares one launch
+    auto next = std::chrono::steady_clock::now();
+    while (b->running.load()) {
+      int rc;
+      {
+        std::lock_guard<std::mutex> tick(b->tick_mu);
+        rc = broker_tick_locked(b, nullptr);
+        if (rc != PEAQ_OK) b->worker_error = g_err;
+      }
+      if (rc != PEAQ_OK) break;
+      next += std::chrono::microseconds(b->period_us);
+      const auto now = std::chrono::steady_clock::now();
+      if (next < now) next = now;
+      std::this_thread::sleep_until(next);
+    }
+  });
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_broker_stats(peaq_broker* b, peaq_broker_stats_t* out) {
+  if (!b || !out) return fail(PEAQ_ERR_ARG, "peaq_broker_stats: NULL argument");
+  std::lock_guard<std::mutex> tick(b->tick_mu);
+  out->ticks = b->n_ticks;
+  out->launches = b->n_launches;
+  out->frames = b->n_frames;
+  out->max_active = b->max_active;
+  out->worker_failed = b->worker_error.empty() ? 0 : 1;
   return PEAQ_OK;
 }

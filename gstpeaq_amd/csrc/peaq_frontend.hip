@@ -241,17 +241,25 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
   const int chan = item % a.channels;
   const unsigned fl = (item / a.channels) % a.frames_per_launch;
   const unsigned pair = item / (a.channels * a.frames_per_launch);
-  const unsigned frame = a.frame0 + fl;
   const unsigned n_ref = a.n_ref ? a.n_ref[pair] : a.n_uniform_ref;
   const unsigned n_test = a.n_test ? a.n_test[pair] : a.n_uniform_test;
-  const unsigned n_frames = a.n_frames ? a.n_frames[pair] : a.n_frames_uniform;
-  if (frame >= n_frames) return;                     // whole workgroup leaves together
+  unsigned frame, frame_origin;
+  if (a.pair_frame0) {                               // broker launch: this pair's own window
+    if (fl >= a.pair_nframes[pair]) return;
+    frame_origin = a.pair_frame0[pair];
+    frame = frame_origin + fl;
+  } else {
+    frame = a.frame0 + fl;
+    frame_origin = a.frame_origin;
+    const unsigned n_frames = a.n_frames ? a.n_frames[pair] : a.n_frames_uniform;
+    if (frame >= n_frames) return;                   // whole workgroup leaves together
+  }
   const size_t pair_off = (size_t)pair * a.pair_stride * a.channels;
   FrameSrc src_ref, src_test;
   src_ref.x = a.ref + pair_off;
   src_test.x = a.test + pair_off;
-  src_ref.s0 = (long long)(frame - a.frame_origin) * kHop + a.off_ref;
-  src_test.s0 = (long long)(frame - a.frame_origin) * kHop + a.off_test;
+  src_ref.s0 = (long long)(frame - frame_origin) * kHop + a.off_ref;
+  src_test.s0 = (long long)(frame - frame_origin) * kHop + a.off_test;
   src_ref.n_valid = (long long)n_ref;
   src_test.n_valid = (long long)n_test;
   src_ref.channels = src_test.channels = a.channels;

@@ -29,6 +29,11 @@ struct FrontendArgs {
   const CommonTables* common;
   const BandTables* bands;      // FFT model, 109 or 55 bands
   double* records;              // [pair][frame - frame0][channel][kRecDoubles]
+  // Broker launches (many live sessions in one grid): every "pair" of the launch is a session
+  // at its own position in its stream.  When set, pair p processes frames
+  // [pair_frame0[p], pair_frame0[p] + pair_nframes[p]) and its buffer starts at that frame.
+  const uint32_t* pair_frame0;
+  const uint32_t* pair_nframes;
 };
 hipError_t launch_frontend(int bands, const FrontendArgs& a, unsigned n_pairs, hipStream_t stream);
 
@@ -42,6 +47,10 @@ struct BackendArgs {
   int advanced;                 // 0: basic (109 bands, 11 MOVs); 1: FFT part of advanced (55 bands)
   const BandTables* bands;
   PairState* state;             // [pair]
+  // broker launches: per-pair frame window and state slot (see FrontendArgs)
+  const uint32_t* pair_frame0;
+  const uint32_t* pair_nframes;
+  const uint32_t* pair_slot;    // state index of pair p (nullptr: p)
 };
 hipError_t launch_backend(const BackendArgs& a, unsigned n_pairs, hipStream_t stream);
 

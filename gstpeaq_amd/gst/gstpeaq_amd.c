@@ -43,6 +43,8 @@ typedef struct _GstPeaqAmd
   gdouble playback_level;
   gint channels;
   peaq_session *session;        /* NULL until caps are known */
+  peaq_broker *broker;          /* set instead of `session` when the process-wide broker serves this element */
+  gint broker_sid;
   gboolean failed;              /* a device error was reported already */
 } GstPeaqAmd;
 
@@ -84,18 +86,63 @@ shared_context (void)
   return ctx;
 }
 
+/* PEAQ_AMD_BROKER=<max sessions>: a process that hosts many `peaq` elements lets ONE broker run
+ * the frames of all of them as one batched launch per tick (include/peaq_amd.h, "broker").  One
+ * broker per channel count, basic model at the default playback level; any other element keeps
+ * its own session. */
+static peaq_broker *
+shared_broker (gint channels)
+{
+  static GMutex lock;
+  static peaq_broker *brokers[3] = { NULL, NULL, NULL };
+  const gchar *max = g_getenv ("PEAQ_AMD_BROKER");
+  peaq_broker *b = NULL;
+  if (!max || atoi (max) <= 0 || channels < 1 || channels > 2)
+    return NULL;
+  g_mutex_lock (&lock);
+  if (!brokers[channels]) {
+    peaq_ctx *ctx = shared_context ();
+    const gchar *period = g_getenv ("PEAQ_AMD_BROKER_PERIOD_US");
+    if (ctx && peaq_broker_create (ctx, channels, 92., atoi (max), &brokers[channels]) == PEAQ_OK) {
+      if (peaq_broker_start (brokers[channels], period ? (unsigned) atoi (period) : 0) != PEAQ_OK)
+        GST_WARNING ("libpeaq_amd: %s", peaq_last_error ());
+    } else {
+      GST_WARNING ("libpeaq_amd: no broker (%s), using one session per element", peaq_last_error ());
+      brokers[channels] = NULL;
+    }
+  }
+  b = brokers[channels];
+  g_mutex_unlock (&lock);
+  return b;
+}
+
+static void
+drop_session (GstPeaqAmd * self)
+{
+  if (self->session)
+    peaq_session_destroy (self->session);
+  if (self->broker)
+    peaq_broker_close (self->broker, self->broker_sid);
+  self->session = NULL;
+  self->broker = NULL;
+}
+
 /* (re)create the engine session: the reference re-allocates all per-channel state
  * whenever caps or the `advanced` property change (gstpeaq.c:519,559,575,586) */
 static gboolean
 renew_session (GstPeaqAmd * self)
 {
   peaq_ctx *ctx;
-  if (self->session) {
-    peaq_session_destroy (self->session);
-    self->session = NULL;
-  }
+  drop_session (self);
   if (self->channels <= 0)
     return TRUE;
+  if (!self->advanced && self->playback_level == 92.) {
+    peaq_broker *b = shared_broker (self->channels);
+    if (b && peaq_broker_open (b, &self->broker_sid) == PEAQ_OK) {
+      self->broker = b;
+      return TRUE;
+    }
+  }
   ctx = shared_context ();
   if (!ctx)
     return FALSE;
@@ -110,6 +157,8 @@ renew_session (GstPeaqAmd * self)
 static gboolean
 read_results (GstPeaqAmd * self, peaq_result * r)
 {
+  if (self->broker && peaq_broker_results (self->broker, self->broker_sid, r) == PEAQ_OK)
+    return TRUE;
   if (!self->session || peaq_session_results (self->session, r) != PEAQ_OK) {
     gint i;
     for (i = 0; i < PEAQ_MOVS_BASIC; i++)
@@ -191,7 +240,7 @@ gst_peaq_amd_set_property (GObject * obj, guint id, const GValue * value, GParam
       self->playback_level = g_value_get_double (value);
       /* the level enters the constant level factors of both ear models
        * (fftearmodel.c:305-314, fbearmodel.c:249-254); a running session keeps its level */
-      if (self->session && self->channels > 0)
+      if ((self->session || self->broker) && self->channels > 0)
         GST_WARNING_OBJECT (self, "playback_level changed mid-stream: applies from the next (re)negotiation");
       GST_OBJECT_UNLOCK (self);
       break;
@@ -230,7 +279,11 @@ gst_peaq_amd_chain (GstPad * pad, GstObject * parent, GstBuffer * buffer)
   }
   GST_OBJECT_LOCK (self);               /* the two streaming threads are serialised, gstpeaq.c:619,658 */
   self->eos[idx] = FALSE;
-  if (!self->session) {
+  if (self->broker) {
+    if (peaq_broker_push (self->broker, self->broker_sid, idx, (const float *) map.data,
+            map.size / (sizeof (float) * self->channels)) != PEAQ_OK)
+      ret = GST_FLOW_ERROR;
+  } else if (!self->session) {
     ret = GST_FLOW_NOT_NEGOTIATED;
   } else if (peaq_session_push (self->session, idx, (const float *) map.data,
           map.size / (sizeof (float) * self->channels)) != PEAQ_OK) {
@@ -257,7 +310,7 @@ gst_peaq_amd_set_caps (GstPeaqAmd * self, GstCaps * caps)
     return FALSE;
   }
   GST_OBJECT_LOCK (self);
-  if (channels != self->channels || !self->session) {
+  if (channels != self->channels || !(self->session || self->broker)) {
     self->channels = channels;
     ok = renew_session (self);
   }
@@ -324,7 +377,8 @@ gst_peaq_amd_change_state (GstElement * element, GstStateChange transition)
   GstPeaqAmd *self = GST_PEAQ_AMD (element);
   if (transition == GST_STATE_CHANGE_PAUSED_TO_READY) {
     /* do_flush + calculate_odg, gstpeaq.c:764-778 */
-    if (self->session && peaq_session_flush (self->session) != PEAQ_OK)
+    if ((self->broker && peaq_broker_flush (self->broker, self->broker_sid) != PEAQ_OK)
+        || (self->session && peaq_session_flush (self->session) != PEAQ_OK))
       GST_ERROR_OBJECT (self, "libpeaq_amd: %s", peaq_last_error ());
     evaluate_odg (self);
   }
@@ -335,8 +389,7 @@ static void
 gst_peaq_amd_finalize (GObject * obj)
 {
   GstPeaqAmd *self = GST_PEAQ_AMD (obj);
-  if (self->session)
-    peaq_session_destroy (self->session);
+  drop_session (self);
   G_OBJECT_CLASS (gst_peaq_amd_parent_class)->finalize (obj);
 }
 
@@ -392,6 +445,8 @@ gst_peaq_amd_init (GstPeaqAmd * self)
   GST_OBJECT_FLAG_SET (self, GST_ELEMENT_FLAG_SINK);
   self->channels = 0;
   self->session = NULL;
+  self->broker = NULL;
+  self->broker_sid = -1;
   self->failed = FALSE;
 }
 

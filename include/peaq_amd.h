@@ -106,6 +106,35 @@ int peaq_session_results (peaq_session *s, peaq_result *out);
  * does not call this) */
 int peaq_session_reset (peaq_session *s);
 
+/* ---- broker: many live sessions, one launch per tick -------------------------
+ * Replaces, for a process hosting MANY `peaq` elements (BASELINE.json
+ * configs[5]), the per-element device work of pad_chain -> do_processing
+ * (gstpeaq.c:596-640): every element owns a session SLOT of one shared broker;
+ * push only queues on the host, and each tick runs the frames that became
+ * ready in all sessions as ONE batched front-end + back-end launch.  The
+ * result of a session is identical to that of a peaq_session fed the same
+ * stream.  Basic model only.  All entry points are thread-safe. */
+typedef struct peaq_broker peaq_broker;
+typedef struct peaq_broker_stats_t {
+  uint64_t ticks;        /* ticks executed (including idle ones)             */
+  uint64_t launches;     /* ticks that launched device work                  */
+  uint64_t frames;       /* FFT frames (per session, not per channel) run    */
+  uint32_t max_active;   /* most sessions served by a single launch          */
+  uint32_t worker_failed;/* the tick thread stopped on a device error        */
+} peaq_broker_stats_t;
+int  peaq_broker_create  (peaq_ctx *ctx, int channels, double playback_level_db, int max_sessions,
+                          peaq_broker **out);
+void peaq_broker_destroy (peaq_broker *b);
+int  peaq_broker_open    (peaq_broker *b, int *session_id);            /* gst_peaq_init / READY->PAUSED      */
+int  peaq_broker_close   (peaq_broker *b, int session_id);             /* finalize                           */
+int  peaq_broker_push    (peaq_broker *b, int session_id, int pad, const float *interleaved, size_t n_samples);
+int  peaq_broker_flush   (peaq_broker *b, int session_id);             /* EOS: do_flush on the next tick     */
+int  peaq_broker_tick    (peaq_broker *b, unsigned *n_active);         /* one batched launch, any thread     */
+int  peaq_broker_results (peaq_broker *b, int session_id, peaq_result *out);  /* drains this session first   */
+int  peaq_broker_start   (peaq_broker *b, unsigned period_us);         /* own tick thread (0 = 2000 us)      */
+int  peaq_broker_stop    (peaq_broker *b);
+int  peaq_broker_stats   (peaq_broker *b, peaq_broker_stats_t *out);
+
 /* ---- batch API ------------------------------------------------------------
  * n_pairs whole pairs, inputs already in device memory as interleaved F32
  * [pair][sample][channel] with a fixed stride of `pair_stride` samples between

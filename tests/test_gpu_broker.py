@@ -1,0 +1,149 @@
+"""-m gpu: the live-pipeline broker (BASELINE.json configs[5]).
+
+Many sessions -- each the stream of one hosted `peaq` element, fed in arbitrary buffer sizes on
+either pad as pad_chain does (gstpeaq.c:613-661) -- share ONE batched launch per tick.  Every
+session must end with exactly the result a whole-pair batch run (and so the reference element,
+see test_gpu_parity.py) gives for its stream.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import cases as case_defs
+import gpu_common as gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _streams(n, channels):
+    out = []
+    for i in range(n):
+        case = dict(kind="synth", seed=100 + i, channels=channels, n=60000 + 7919 * (i % 11),
+                    test_trim=(0, 1234, 5, 2047)[i % 4] if i % 3 else 0)
+        out.append(case_defs.make_inputs(case))
+    return out
+
+
+def _same(got, exp, where):
+    assert got["frames"] == exp["frames"], where
+    np.testing.assert_allclose(got["movs"], exp["movs"], rtol=1e-12, atol=0, equal_nan=True, err_msg=str(where))
+    for k, tol in (("di", 1e-12), ("odg", 1e-12), ("totalsnr", 1e-9)):
+        if np.isnan(exp[k]):
+            assert np.isnan(got[k]), (where, k)
+        else:
+            assert abs(got[k] - exp[k]) <= tol, (where, k, got[k], exp[k])
+
+
+def _feed(broker, sid, ref, test, rng, tick_every=None):
+    pr = pt = 0
+    k_calls = 0
+    while pr < len(ref) or pt < len(test):
+        if pr < len(ref):
+            k = int(rng.integers(1, 6000))
+            broker.push(sid, 0, ref[pr:pr + k])
+            pr += k
+        if pt < len(test):
+            k = int(rng.integers(1, 6000))
+            broker.push(sid, 1, test[pt:pt + k])
+            pt += k
+        k_calls += 1
+        if tick_every and k_calls % tick_every == 0:
+            broker.tick()
+    broker.flush(sid)
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_broker_sessions_equal_batch(channels):
+    import gstpeaq_amd
+    n = 37
+    streams = _streams(n, channels)
+    whole = gpu.run_batch(streams, False, channels)
+    b = gstpeaq_amd.Broker(gpu.ctx(), channels, max_sessions=64)
+    sids = [b.open() for _ in range(n)]
+    assert sorted(sids) == list(range(n))
+    rng = np.random.default_rng(5)
+    # interleave the sessions: round-robin chunks, a tick now and then
+    pos = [[0, 0] for _ in range(n)]
+    live = set(range(n))
+    rounds = 0
+    while live:
+        for i in list(live):
+            ref, test = streams[i]
+            for pad, sig in ((0, ref), (1, test)):
+                if pos[i][pad] < len(sig):
+                    k = int(rng.integers(1, 7000))
+                    b.push(sids[i], pad, sig[pos[i][pad]:pos[i][pad] + k])
+                    pos[i][pad] += k
+            if pos[i][0] >= len(ref) and pos[i][1] >= len(test):
+                b.flush(sids[i])
+                live.discard(i)
+        rounds += 1
+        if rounds % 2 == 0:
+            b.tick()
+    for i in range(n):
+        _same(b.results(sids[i]), whole[i], i)
+    st = b.stats()
+    assert st["max_active"] > 1 and st["launches"] < sum(w["frames"] for w in whole)   # really batched
+    assert st["frames"] == sum(w["frames"] for w in whole)
+    b.close()
+
+
+def test_broker_tick_thread_and_slot_reuse():
+    import gstpeaq_amd
+    channels = 2
+    streams = _streams(12, channels)
+    whole = gpu.run_batch(streams, False, channels)
+    b = gstpeaq_amd.Broker(gpu.ctx(), channels, max_sessions=4)
+    b.start(500)
+    with pytest.raises(gstpeaq_amd.PeaqError):
+        b.start(500)                                    # already running
+    results = [None] * len(streams)
+    errors = []
+
+    def element(worker):                                # one thread = one pipeline's streaming thread
+        try:
+            rng = np.random.default_rng(worker)
+            for i in range(worker, len(streams), 4):
+                sid = b.open()
+                _feed(b, sid, *streams[i], rng)
+                results[i] = b.results(sid)
+                b.close_session(sid)                    # the slot is reused by the next stream
+        except Exception as e:                          # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=element, args=(w,)) for w in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    b.stop()
+    assert not errors, errors
+    for i, got in enumerate(results):
+        _same(got, whole[i], i)
+    assert b.stats()["worker_failed"] == 0
+    b.close()
+
+
+def test_broker_argument_and_state_errors():
+    import gstpeaq_amd
+    b = gstpeaq_amd.Broker(gpu.ctx(), 1, max_sessions=2)
+    s0, s1 = b.open(), b.open()
+    with pytest.raises(gstpeaq_amd.PeaqError, match="in use"):
+        b.open()
+    with pytest.raises(gstpeaq_amd.PeaqError):
+        b.push(7, 0, np.zeros(10, np.float32))
+    with pytest.raises(gstpeaq_amd.PeaqError):
+        b.push(s0, 2, np.zeros(10, np.float32))
+    b.close_session(s1)
+    with pytest.raises(gstpeaq_amd.PeaqError, match="not open"):
+        b.push(s1, 0, np.zeros(10, np.float32))
+    # an empty session reports what an element without data reports: no frames, NaN averages
+    r = b.results(s0)
+    assert r["frames"] == 0
+    assert b.tick() == 0
+    with pytest.raises(gstpeaq_amd.PeaqError):
+        gstpeaq_amd.Broker(gpu.ctx(), 3, max_sessions=2)
+    with pytest.raises(gstpeaq_amd.PeaqError):
+        gstpeaq_amd.Broker(gpu.ctx(), 1, max_sessions=0)
+    b.close()

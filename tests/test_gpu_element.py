@@ -90,3 +90,28 @@ def test_cli_on_wav_files(tmp_path, advanced):
     lines = out.stdout.strip().splitlines()
     assert lines[-2] == "Objective Difference Grade: %.3f" % exp["odg"]      # peaq.c:217-220
     assert lines[-1] == "Distortion Index: %.3f" % exp["di"]
+
+
+def test_many_elements_share_the_broker():
+    """with PEAQ_AMD_BROKER set, every `peaq` element of the process becomes a
+    session of one broker and their frames run as batched launches; each element still prints
+    exactly what the reference prints for its pipeline (runtest-1.0.sh:8-50)."""
+    args = []
+    n = 8
+    for i in range(n):
+        if i % 2 == 0:
+            args += ["audiotestsrc", f"name=s{i}", "num-buffers=128", "freq=440", "tee", f"name=t{i}",
+                     "queue", f"name=qa{i}", "queue", f"name=qb{i}", "peaq", f"name=p{i}",
+                     f"s{i}.src!t{i}.sink", f"t{i}.src_0!qa{i}.sink", f"t{i}.src_1!qb{i}.sink",
+                     f"qa{i}.src!p{i}.ref", f"qb{i}.src!p{i}.test"]
+        else:
+            args += ["audiotestsrc", f"name=s{i}", "num-buffers=128", "wave=saw", "freq=440",
+                     "audiotestsrc", f"name=r{i}", "num-buffers=128", "wave=triangle", "freq=440",
+                     "peaq", f"name=p{i}", f"s{i}.src!p{i}.ref", f"r{i}.src!p{i}.test"]
+    cmd = ["gst-launch-1.0", "-q", f"--gst-plugin-load={gst_env.PLUGIN}", *args]
+    env = gst_env.env()
+    env["PEAQ_AMD_BROKER"] = "16"
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    odgs = sorted(l.split()[3] for l in out.stdout.splitlines() if l.startswith("Objective Difference Grade:"))
+    assert odgs == sorted(["0.171"] * (n // 2) + ["-2.007"] * (n // 2)), out.stdout[-1500:]
