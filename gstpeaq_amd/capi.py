@@ -61,6 +61,10 @@ def load_library():
     if not so.exists():
         raise PeaqError(f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(the HIP extension is required, there is no CPU path)")
+    # PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so); whichever copy is mapped first
+    # serves the whole process, and torch finds no GPU when it is not its own.  This binding uses
+    # torch for device memory and streams anyway, so let it load its runtime first.
+    import torch  # noqa: F401
     L = C.CDLL(str(so))
     vp, dp, fp, u32p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
     L.peaq_last_error.restype = C.c_char_p
