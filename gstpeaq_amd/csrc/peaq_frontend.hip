@@ -230,7 +230,8 @@ template <int NB>
 __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63;
-  const int sig = threadIdx.x >> 6;                  // 0 = reference wave, 1 = test wave
+  // 0 = reference wave, 1 = test wave; wave-uniform, so keep it (and all that hangs on it) scalar
+  const int sig = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* unit = lds + sig * kUnitDoubles;
   double* scratch = unit + kOffScratch;
   const CommonTables* __restrict__ ct = a.common;
@@ -303,9 +304,11 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     } else {
       // quiet frame: stage |x| (8 KiB, start of the still unused FFT buffer) and decide exactly
       float* ax = reinterpret_cast<float*>(unit);
+      int lane_q = lane;                             // opaque copy: recompute the indices here rather
+      asm volatile("" : "+v"(lane_q));               // than keep 16 of them alive from the first loop
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = lane + 64 * r;
+        const int n = lane_q + 64 * r;
         float x0, x1;
         src.load2(n, x0, x1);
         reinterpret_cast<float2*>(ax)[n] = make_float2(fabsf(x0), fabsf(x1));
@@ -315,6 +318,9 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
       wave_lds_fence();
     }
   }
+
+  if (lane == 0)                                     // out now: nothing of this stays live over the transform
+    rec[sig ? kRecFlagsTest : kRecFlagsRef] = (double)(above | (energy_flag << 1));
 
   double pspec[16];                                  // unweighted power spectrum, bin lane + 64 q
   frame_power_spectrum(z, pspec, unit, lane, ct, a.level_factor);
@@ -429,12 +435,6 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     *reinterpret_cast<double2*>(rec + (sig ? kRecUnsmTest : kRecUnsmRef) + b0) = make_double2(unsm[0], unsm[1]);
     *reinterpret_cast<double2*>(rec + (sig ? kRecLoudTest : kRecLoudRef) + b0) = make_double2(loud[0], loud[1]);
   }
-  if (lane == 0) {
-    if (sig == 0)
-      rec[kRecFlagsRef] = (double)(above | (energy_flag << 1));
-    else
-      rec[kRecFlagsTest] = (double)(energy_flag << 1);
-  }
 
   __syncthreads();                                   // both spectra are in LDS
   const double* pw_ref = lds + kOffPw;
@@ -490,9 +490,11 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     if (b0 < kBandStride) *reinterpret_cast<double2*>(rec + kRecNoise + b0) = make_double2(nib[0], nib[1]);
     // ---- totalsnr energies over the hop (gstpeaq.c:913-918; float products) --------
     double se = 0., ne = 0.;
+    int lane_q = lane;                               // opaque copy, see above
+    asm volatile("" : "+v"(lane_q));
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const int n = lane + 64 * r;
+      const int n = lane_q + 64 * r;
       float r0, r1, t0, t1;
       src_ref.load2(n, r0, r1);
       src_test.load2(n, t0, t1);
