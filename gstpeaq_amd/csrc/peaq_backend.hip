@@ -30,28 +30,34 @@ constexpr int kLdsBands = 128;      // 2 bands x 64 lanes: every lane may store,
 // ---------------------------------------------------------------------------
 // MOV accumulator owned by one lane (movaccum.c)
 // ---------------------------------------------------------------------------
+// The twelve fields live in LDS (field k of the accumulator at f[k * kAccLdsStride]); they are
+// touched once per frame, registers are better spent on the band state.
+constexpr int kAccLdsStride = 16;
 struct LaneAcc {
-  double num, den, num2, p0, p1, p2, mx, filt, s_num, s_den, s_num2, s_mx;
+  double* f;
   int mode, status;
+  enum { NUM, DEN, NUM2, P0, P1, P2, MX, FILT, S_NUM, S_DEN, S_NUM2, S_MX };
+  __device__ __forceinline__ double& at(int k) const { return f[k * kAccLdsStride]; }
 
-  __device__ __forceinline__ void load(const double* f, int mode_, int status_) {
-    num = f[0]; den = f[1]; num2 = f[2]; p0 = f[3]; p1 = f[4]; p2 = f[5];
-    mx = f[6]; filt = f[7]; s_num = f[8]; s_den = f[9]; s_num2 = f[10]; s_mx = f[11];
+  __device__ __forceinline__ void load(double* lds, const double* g, int mode_, int status_) {
+    f = lds;
+#pragma unroll
+    for (int k = 0; k < kAccFields; ++k) at(k) = g[k];
     mode = mode_;
     status = status_;
   }
-  __device__ __forceinline__ void store(double* f) const {
-    f[0] = num; f[1] = den; f[2] = num2; f[3] = p0; f[4] = p1; f[5] = p2;
-    f[6] = mx; f[7] = filt; f[8] = s_num; f[9] = s_den; f[10] = s_num2; f[11] = s_mx;
+  __device__ __forceinline__ void store(double* g) const {
+#pragma unroll
+    for (int k = 0; k < kAccFields; ++k) g[k] = at(k);
   }
   // movaccum.c:317-362
   __device__ __forceinline__ void set_tentative(bool tentative) {
     if (tentative) {
       if (status == kNormal) {
-        s_num = num;
-        s_den = den;
-        s_num2 = num2;
-        s_mx = mx;                 // FILTERED_MAX: only `max`, not the filter state (:343-346)
+        at(S_NUM) = at(NUM);
+        at(S_DEN) = at(DEN);
+        at(S_NUM2) = at(NUM2);
+        at(S_MX) = at(MX);         // FILTERED_MAX: only `max`, not the filter state (:343-346)
         status = kTentative;
       }
     } else {
@@ -64,39 +70,42 @@ struct LaneAcc {
     switch (mode) {
       case kRms:
         w *= w;
-        num += w * val * val;
-        den += w;
+        at(NUM) += w * val * val;
+        at(DEN) += w;
         break;
       case kRmsAsym:
-        num += val * val;
-        num2 += w * w;
-        den += 1.;
+        at(NUM) += val * val;
+        at(NUM2) += w * w;
+        at(DEN) += 1.;
         break;
       case kAvg:
       case kAvgLog:
       case kAdb:
-        num += w * val;
-        den += w;
+        at(NUM) += w * val;
+        at(DEN) += w;
         break;
       case kAvgWindow: {
         const double sq = sqrt(val);
+        const double p0 = at(P0), p1 = at(P1), p2 = at(P2);
         if (!isnan(p0)) {
           double ws = ((sq + p0) + p1) + p2;
           ws /= 4.;
           ws *= ws;
           ws *= ws;
-          num += ws;
-          den += 1.;
+          at(NUM) += ws;
+          at(DEN) += 1.;
         }
-        p0 = p1;
-        p1 = p2;
-        p2 = sq;
+        at(P0) = p1;
+        at(P1) = p2;
+        at(P2) = sq;
         break;
       }
-      case kFilteredMax:
-        filt = 0.9 * filt + 0.1 * val;
-        if (filt > mx) mx = filt;
+      case kFilteredMax: {
+        const double filt = 0.9 * at(FILT) + 0.1 * val;
+        at(FILT) = filt;
+        if (filt > at(MX)) at(MX) = filt;
         break;
+      }
     }
   }
 };
@@ -140,10 +149,42 @@ struct BandLane {
   __device__ __forceinline__ bool valid(int s) const { return band(s) < NB; }
 };
 
+// Per-band constants as the building blocks see them: straight from the tables in global memory
+// (filter-bank back end), or from a copy in LDS (FFT back end: nine tables x two bands would
+// otherwise sit in 36 registers for the whole frame loop -- or be spilled).
+struct GlobalTabs {
+  const BandTables* __restrict__ p;
+  __device__ __forceinline__ double adapt_tc(int b) const { return p->adapt_tc[b]; }
+  __device__ __forceinline__ double ear_tc(int b) const { return p->ear_tc[b]; }
+  __device__ __forceinline__ double threshold(int b) const { return p->threshold[b]; }
+  __device__ __forceinline__ double loud_factor(int b) const { return p->loud_factor[b]; }
+  __device__ __forceinline__ double exc_threshold(int b) const { return p->exc_threshold[b]; }
+  __device__ __forceinline__ double internal_noise(int b) const { return p->internal_noise[b]; }
+  __device__ __forceinline__ double noise_pow03(int b) const { return p->noise_pow03[b]; }
+  __device__ __forceinline__ double mask_diff(int b) const { return p->mask_diff[b]; }
+  __device__ __forceinline__ double deriv_factor() const { return p->deriv_factor; }
+};
+enum { T_ADAPT, T_EAR, T_THR, T_LOUDF, T_EXCTHR, T_INOISE, T_NPOW03, T_MASK, T_COUNT };
+struct LdsTabs {
+  const double* t;                  // [T_COUNT][kBandStride] in LDS
+  int off;                          // 0, but opaque to the compiler (re-read per frame, not hoisted)
+  double deriv;
+  __device__ __forceinline__ double at(int tab, int b) const { return t[off + tab * kBandStride + b]; }
+  __device__ __forceinline__ double adapt_tc(int b) const { return at(T_ADAPT, b); }
+  __device__ __forceinline__ double ear_tc(int b) const { return at(T_EAR, b); }
+  __device__ __forceinline__ double threshold(int b) const { return at(T_THR, b); }
+  __device__ __forceinline__ double loud_factor(int b) const { return at(T_LOUDF, b); }
+  __device__ __forceinline__ double exc_threshold(int b) const { return at(T_EXCTHR, b); }
+  __device__ __forceinline__ double internal_noise(int b) const { return at(T_INOISE, b); }
+  __device__ __forceinline__ double noise_pow03(int b) const { return at(T_NPOW03, b); }
+  __device__ __forceinline__ double mask_diff(int b) const { return at(T_MASK, b); }
+  __device__ __forceinline__ double deriv_factor() const { return deriv; }
+};
+
 // leveladapter.c:243-340.  e_ref/e_test: excitation patterns of this frame.
 // st: [6][SLOTS] state (filt_ref, filt_test, num, den, pattcorr_ref, pattcorr_test)
-template <int NB, int SLOTS>
-__device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const BandTables* __restrict__ bt,
+template <int NB, int SLOTS, class TAB>
+__device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const TAB& bt,
                                             const double (&e_ref)[SLOTS], const double (&e_test)[SLOTS],
                                             double (&st)[6][SLOTS], double* pa_lds /* [2][kLdsBands] */,
                                             double (&ad_ref)[SLOTS], double (&ad_test)[SLOTS]) {
@@ -151,7 +192,7 @@ __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     if (bl.valid(s)) {
-      const double a = bt->adapt_tc[bl.band(s)];
+      const double a = bt.adapt_tc(bl.band(s));
       st[0][s] = a * st[0][s] + (1 - a) * e_ref[s];          // (42)/(43) in BS.1387
       st[1][s] = a * st[1][s] + (1 - a) * e_test[s];
       num += sqrt(st[0][s] * st[1][s]);                      // (45)
@@ -173,7 +214,7 @@ __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const
     }
     double pr = 0., pt = 0.;
     if (bl.valid(s)) {
-      const double a = bt->adapt_tc[bl.band(s)];
+      const double a = bt.adapt_tc(bl.band(s));
       st[2][s] = a * st[2][s] + lc_test[s] * lc_ref[s];      // (48): no (1-a) gain, leveladapter.c:293-298
       st[3][s] = a * st[3][s] + lc_ref[s] * lc_ref[s];
       if (st[2][s] >= st[3][s]) {                            // (49)
@@ -204,7 +245,7 @@ __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const
       }
       rr /= (m1 + m2 + 1);
       rt /= (m1 + m2 + 1);
-      const double a = bt->adapt_tc[k];
+      const double a = bt.adapt_tc(k);
       st[4][s] = a * st[4][s] + (1 - a) * rr;
       st[5][s] = a * st[5][s] + (1 - a) * rt;
       ad_ref[s] = lc_ref[s] * st[4][s];                      // (52)/(53)
@@ -215,16 +256,16 @@ __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const
 }
 
 // modpatt.c:223-251; st: prev_loud, filt_loud, filt_dloud
-template <int NB, int SLOTS>
-__device__ __forceinline__ void modulation(const BandLane<NB, SLOTS>& bl, const BandTables* __restrict__ bt,
+template <int NB, int SLOTS, class TAB>
+__device__ __forceinline__ void modulation(const BandLane<NB, SLOTS>& bl, const TAB& bt,
                                            const double (&loud)[SLOTS], double (&st)[3][SLOTS],
                                            double (&mod)[SLOTS]) {
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     mod[s] = 0.;
     if (bl.valid(s)) {
-      const double a = bt->adapt_tc[bl.band(s)];
-      const double dl = bt->deriv_factor * fabs(loud[s] - st[0][s]);
+      const double a = bt.adapt_tc(bl.band(s));
+      const double dl = bt.deriv_factor() * fabs(loud[s] - st[0][s]);
       st[2][s] = a * st[2][s] + (1 - a) * dl;
       st[1][s] = a * st[1][s] + (1. - a) * loud[s];
       mod[s] = st[2][s] / (1. + st[1][s] / 0.3);
@@ -234,16 +275,16 @@ __device__ __forceinline__ void modulation(const BandLane<NB, SLOTS>& bl, const 
 }
 
 // earmodel.c:891-907
-template <int NB, int SLOTS>
-__device__ __forceinline__ double total_loudness(const BandLane<NB, SLOTS>& bl, const BandTables* __restrict__ bt,
+template <int NB, int SLOTS, class TAB>
+__device__ __forceinline__ double total_loudness(const BandLane<NB, SLOTS>& bl, const TAB& bt,
                                                  const double (&exc)[SLOTS]) {
   double t = 0.;
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     if (bl.valid(s)) {
       const int b = bl.band(s);
-      const double thr = bt->threshold[b];
-      const double l = bt->loud_factor[b] * (pow_pos(1. - thr + thr * exc[s] / bt->exc_threshold[b], 0.23) - 1.);
+      const double thr = bt.threshold(b);
+      const double l = bt.loud_factor(b) * (pow_pos(1. - thr + thr * exc[s] / bt.exc_threshold(b), 0.23) - 1.);
       t += fmax(l, 0.);
     }
   }
@@ -251,8 +292,8 @@ __device__ __forceinline__ double total_loudness(const BandLane<NB, SLOTS>& bl, 
 }
 
 // movs.c:709-743
-template <int NB, int SLOTS>
-__device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, const BandTables* __restrict__ bt,
+template <int NB, int SLOTS, class TAB>
+__device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, const TAB& bt,
                                                  double alpha, double thres_fac, double s0, double nl_min,
                                                  const double (&mod_ref)[SLOTS], const double (&mod_test)[SLOTS],
                                                  const double (&e_ref)[SLOTS], const double (&e_test)[SLOTS]) {
@@ -262,7 +303,7 @@ __device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, 
     if (bl.valid(s)) {
       const double sref = thres_fac * mod_ref[s] + s0;
       const double stest = thres_fac * mod_test[s] + s0;
-      const double ethres = bt->internal_noise[bl.band(s)];
+      const double ethres = bt.internal_noise(bl.band(s));
       const double beta = exp(-alpha * (e_test[s] - e_ref[s]) / e_ref[s]);
       nl += pow_pos(ethres / stest, 0.23) *
             (pow_pos(1. + fmax(stest * e_test[s] - sref * e_ref[s], 0.) / (ethres + sref * e_ref[s] * beta), 0.23) - 1.);
@@ -273,8 +314,8 @@ __device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, 
 }
 
 // movs.c:224-251: returns d1 (un-normalised), d2, weight
-template <int NB, int SLOTS>
-__device__ __forceinline__ void mod_difference(const BandLane<NB, SLOTS>& bl, const BandTables* __restrict__ bt,
+template <int NB, int SLOTS, class TAB>
+__device__ __forceinline__ void mod_difference(const BandLane<NB, SLOTS>& bl, const TAB& bt,
                                                double lev_wt, const double (&mr)[SLOTS], const double (&mt)[SLOTS],
                                                const double (&loud_ref)[SLOTS], double& d1, double& d2, double& wt) {
   double a1 = 0., a2 = 0., aw = 0.;
@@ -284,7 +325,7 @@ __device__ __forceinline__ void mod_difference(const BandLane<NB, SLOTS>& bl, co
       const double diff = fabs(mr[s] - mt[s]);
       a1 += diff / (1. + mr[s]);
       a2 += (mt[s] >= mr[s] ? 1. : .1) * diff / (0.01 + mr[s]);
-      aw += loud_ref[s] / (loud_ref[s] + lev_wt * bt->noise_pow03[bl.band(s)]);
+      aw += loud_ref[s] / (loud_ref[s] + lev_wt * bt.noise_pow03(bl.band(s)));
     }
   }
   d1 = wave_sum(a1);
@@ -304,9 +345,7 @@ struct BackendShared {
   double pa[2][2][kLdsBands];       // [wave][ref/test][band] pattern-adaptation ratios
   double pc[2][kLdsBands];          // detection probabilities per channel
   double qc[2][kLdsBands];
-  double acc_val[2][kMaxAcc];
-  double acc_w[2][kMaxAcc];
-  int acc_mask[2];
+  double acc[2][kAccFields][kAccLdsStride];   // [channel][field][accumulator]
   int gate[2];
 };
 
@@ -315,13 +354,22 @@ struct BackendShared {
 template <int NB, bool ADV>
 __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
   __shared__ BackendShared sh;
+  __shared__ double sh_tab[T_COUNT * kBandStride];
   constexpr int SLOTS = 2;
   const int lane = threadIdx.x & 63;
-  const int chan = threadIdx.x >> 6;
+  const int chan = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
   const int channels = a.channels;                  // == blockDim.x / 64
   const unsigned pair = blockIdx.x;
-  const BandTables* __restrict__ bt = a.bands;
   const BandLane<NB, SLOTS> bl{lane};
+  {
+    const BandTables* __restrict__ g = a.bands;
+    const double* const src[T_COUNT] = {g->adapt_tc, g->ear_tc, g->threshold, g->loud_factor, g->exc_threshold,
+                                        g->internal_noise, g->noise_pow03, g->mask_diff};
+#pragma unroll
+    for (int t = 0; t < T_COUNT; ++t)
+      for (int i = threadIdx.x; i < kBandStride; i += blockDim.x) sh_tab[t * kBandStride + i] = src[t][i];
+  }
+  LdsTabs bt{sh_tab, 0, a.bands->deriv_factor};
   PairState* __restrict__ ps = a.state + (a.pair_slot ? a.pair_slot[pair] : pair);
   ChannelState* __restrict__ cs = &ps->ch[chan];
 
@@ -336,6 +384,7 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
     if (f_end > n_frames) f_end = n_frames;
   }
   if (f_begin >= f_end) return;
+  __syncthreads();                                   // the table copy is complete
 
   // ---- recurrent state -> registers -----------------------------------------------
   double sm[2][SLOTS];                               // smeared excitation filters (ref, test)
@@ -357,12 +406,14 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
   LaneAcc acc;
   {
     const int i = lane < kMaxAcc ? lane : 0;
-    acc.load(cs->acc[i], acc_mode(ADV, i), ps->status[i]);
+    acc.load(&sh.acc[chan][0][lane < kAccLdsStride ? lane : kAccLdsStride - 1], cs->acc[i], acc_mode(ADV, i),
+             ps->status[i]);   // lanes beyond the 11 accumulators work on dummy slots
   }
   unsigned loud_reached = ps->loudness_reached;
   double sig_e = ps->sig_energy, noise_e = ps->noise_energy;
 
   for (unsigned frame = f_begin; frame < f_end; ++frame) {
+    asm volatile("" : "+v"(bt.off));                 // the tables are re-read from LDS where they are used
     const double* __restrict__ rec0 =
         a.records + ((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels) * kRecDoubles;
     const double* __restrict__ rec = rec0 + (size_t)chan * kRecDoubles;
@@ -396,7 +447,7 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       const int b = bl.band(s) < kBandStride ? bl.band(s) : 0;
-      const double ac = bt->ear_tc[b];
+      const double ac = bt.ear_tc(b);
       sm[0][s] = ac * sm[0][s] + (1. - ac) * ur[s];
       er[s] = sm[0][s] > ur[s] ? sm[0][s] : ur[s];
       if (!ADV) {
@@ -485,7 +536,7 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
 #pragma unroll
       for (int s = 0; s < SLOTS; ++s) {
         if (bl.valid(s)) {
-          const double m = er[s] / bt->mask_diff[bl.band(s)];
+          const double m = er[s] / bt.mask_diff(bl.band(s));
           const double r = nz[s] / m;
           nsum += r;
           if (r > nmax) nmax = r;
@@ -584,6 +635,7 @@ hipError_t launch_backend(const BackendArgs& a, unsigned n_pairs, hipStream_t st
 // ---------------------------------------------------------------------------
 struct FbBackendShared {
   double pa[2][2][kLdsBands];
+  double acc[2][kAccFields][kAccLdsStride];
   int gate[2];
 };
 
@@ -594,7 +646,7 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
   const int chan = threadIdx.x >> 6;
   const int channels = a.channels;
   const unsigned pair = blockIdx.x;
-  const BandTables* __restrict__ bt = a.bands;
+  const GlobalTabs bt{a.bands};
   const BandLane<NB, SLOTS> bl{lane};
   PairState* __restrict__ ps = a.state + pair;
   ChannelState* __restrict__ cs = &ps->ch[chan];
@@ -615,7 +667,8 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
   LaneAcc acc;
   {
     const int i = lane < kMaxAcc ? lane : 0;
-    acc.load(cs->acc[i], acc_mode(true, i), ps->status[i]);
+    acc.load(&sh.acc[chan][0][lane < kAccLdsStride ? lane : kAccLdsStride - 1], cs->acc[i], acc_mode(true, i),
+             ps->status[i]);
   }
   const bool owns = lane == MA_RMSMOD || lane == MA_NLASYM || lane == MA_LINDIST;
   unsigned loud_reached = ps->loudness_reached;
