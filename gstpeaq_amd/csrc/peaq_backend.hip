@@ -26,6 +26,8 @@
 namespace peaq {
 
 constexpr int kLdsBands = 128;      // 2 bands x 64 lanes: every lane may store, only valid bands are read
+// pattern-adaptation ratios in LDS: kPaPad zeros, 128 band slots (zero beyond the last band), spare
+constexpr int kPaPad = 4, kPaStride = kPaPad + kLdsBands + 4;
 
 // ---------------------------------------------------------------------------
 // MOV accumulator owned by one lane (movaccum.c)
@@ -186,7 +188,7 @@ struct LdsTabs {
 template <int NB, int SLOTS, class TAB>
 __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const TAB& bt,
                                             const double (&e_ref)[SLOTS], const double (&e_test)[SLOTS],
-                                            double (&st)[6][SLOTS], double* pa_lds /* [2][kLdsBands] */,
+                                            double (&st)[6][SLOTS], double* pa_lds /* [2][kPaStride], zero padded */,
                                             double (&ad_ref)[SLOTS], double (&ad_test)[SLOTS]) {
   double num = 0., den = 0.;
 #pragma unroll
@@ -225,8 +227,8 @@ __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const
         pt = 1.;
       }
     }
-    pa_lds[bl.band(s)] = pr;
-    pa_lds[kLdsBands + bl.band(s)] = pt;
+    pa_lds[kPaPad + bl.band(s)] = pr;                        // 0 for the slots beyond the last band
+    pa_lds[kPaStride + kPaPad + bl.band(s)] = pt;
   }
   wave_lds_fence();
   constexpr int M1 = NB / 36, M2 = NB / 25;                  // leveladapter.c:315-316
@@ -238,10 +240,14 @@ __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const
       const int k = bl.band(s);
       const int m1 = k < M1 ? k : M1;
       const int m2 = (NB - k - 1) < M2 ? (NB - k - 1) : M2;
+      // (50)/(51): window [k - m1, k + m2] summed in ascending order like the reference.  The
+      // array is zero outside [0, NB), so the full window [k - M1, k + M2] gives the same sums
+      // bit for bit (x + 0 = x) with compile-time offsets from one address.
       double rr = 0., rt = 0.;
-      for (int l = k - m1; l <= k + m2; ++l) {               // (50)/(51)
-        rr += pa_lds[l];
-        rt += pa_lds[kLdsBands + l];
+#pragma unroll
+      for (int j = -M1; j <= M2; ++j) {
+        rr += pa_lds[kPaPad + k + j];
+        rt += pa_lds[kPaStride + kPaPad + k + j];
       }
       rr /= (m1 + m2 + 1);
       rt /= (m1 + m2 + 1);
@@ -342,10 +348,11 @@ enum { MB_BW_REF, MB_BW_TEST, MB_NMR, MB_WINMOD, MB_ADB, MB_EHS, MB_AVGMOD1, MB_
 enum { MA_RMSMOD, MA_NLASYM, MA_SEGNMR, MA_EHS, MA_LINDIST };   // gstpeaq.c:86-93
 
 struct BackendShared {
-  double pa[2][2][kLdsBands];       // [wave][ref/test][band] pattern-adaptation ratios
+  double pa[2][2][kPaStride];       // [wave][ref/test][pad + band] pattern-adaptation ratios
   double pc[2][kLdsBands];          // detection probabilities per channel
   double qc[2][kLdsBands];
   double acc[2][kAccFields][kAccLdsStride];   // [channel][field][accumulator]
+  double energy[2];                 // totalsnr: signal and noise energy so far (lane 0 of channel 0)
   int gate[2];
 };
 
@@ -384,6 +391,7 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
     if (f_end > n_frames) f_end = n_frames;
   }
   if (f_begin >= f_end) return;
+  if (lane < kPaPad) sh.pa[chan][0][lane] = sh.pa[chan][1][lane] = 0.;
   __syncthreads();                                   // the table copy is complete
 
   // ---- recurrent state -> registers -----------------------------------------------
@@ -410,7 +418,10 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
              ps->status[i]);   // lanes beyond the 11 accumulators work on dummy slots
   }
   unsigned loud_reached = ps->loudness_reached;
-  double sig_e = ps->sig_energy, noise_e = ps->noise_energy;
+  if (chan == 0 && lane == 0) {
+    sh.energy[0] = ps->sig_energy;
+    sh.energy[1] = ps->noise_energy;
+  }
 
   for (unsigned frame = f_begin; frame < f_end; ++frame) {
     asm volatile("" : "+v"(bt.off));                 // the tables are re-read from LDS where they are used
@@ -578,9 +589,9 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
       route(MB_MFPD, p_bin, 1.);
     }
     // ---- totalsnr (gstpeaq.c:913-918) --------------------------------------------------------
-    if (chan == 0) {
-      sig_e += rec0[kRecSigE] + (channels == 2 ? rec0[kRecDoubles + kRecSigE] : 0.);
-      noise_e += rec0[kRecNoiseE] + (channels == 2 ? rec0[kRecDoubles + kRecNoiseE] : 0.);
+    if (chan == 0 && lane == 0) {
+      sh.energy[0] += rec0[kRecSigE] + (channels == 2 ? rec0[kRecDoubles + kRecSigE] : 0.);
+      sh.energy[1] += rec0[kRecNoiseE] + (channels == 2 ? rec0[kRecDoubles + kRecNoiseE] : 0.);
     }
     // ---- accumulate: lane i owns accumulator i --------------------------------------------------
     if (my_hit) acc.add(my_v, my_w);
@@ -614,8 +625,8 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
   if (chan == 0 && lane == 0) {
     ps->frame_counter = f_end;
     if (!ADV) ps->loudness_reached = loud_reached;
-    ps->sig_energy = sig_e;
-    ps->noise_energy = noise_e;
+    ps->sig_energy = sh.energy[0];
+    ps->noise_energy = sh.energy[1];
   }
 }
 
@@ -634,7 +645,7 @@ hipError_t launch_backend(const BackendArgs& a, unsigned n_pairs, hipStream_t st
 // one band per lane, blocks of 192 samples in order.
 // ---------------------------------------------------------------------------
 struct FbBackendShared {
-  double pa[2][2][kLdsBands];
+  double pa[2][2][kPaStride];
   double acc[2][kAccFields][kAccLdsStride];
   int gate[2];
 };
@@ -670,6 +681,8 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
     acc.load(&sh.acc[chan][0][lane < kAccLdsStride ? lane : kAccLdsStride - 1], cs->acc[i], acc_mode(true, i),
              ps->status[i]);
   }
+  if (lane < kPaPad) sh.pa[chan][0][lane] = sh.pa[chan][1][lane] = 0.;
+  wave_lds_fence();
   const bool owns = lane == MA_RMSMOD || lane == MA_NLASYM || lane == MA_LINDIST;
   unsigned loud_reached = ps->loudness_reached;
 
