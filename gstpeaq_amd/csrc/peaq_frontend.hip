@@ -389,17 +389,17 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
   }
   wave_lds_fence();
   // upward spreading, Kabal (27): E2[j] += Ene[i] * aUCEe[i]^(j-i) for j > i.
-  // One LDS atomic add per (source band, step); the targets of one instruction
-  // are distinct, so there is no contention.
+  // The lane's two bands 2 lane and 2 lane + 1 reach target 2 lane + s after s and s - 1 steps:
+  // their contributions are added in registers and leave as ONE LDS atomic per step; the
+  // targets of one instruction are distinct (consecutive slots of one parity), no contention.
   {
-    double r0 = ene[0], r1 = ene[1];
+    double r0 = ene[0] * ae[0], r1 = ene[1];         // r0 = Ene[2 lane] a^s, r1 = Ene[2 lane + 1] a^(s-1)
+    atomicAdd(&e2up[128 + lane], r0);                // s = 1: target 2 lane + 1, band 2 lane alone
 #pragma unroll 12
-    for (int s = 1; s < NB; ++s) {
+    for (int s = 2; s <= NB; ++s) {
       r0 *= ae[0];
       r1 *= ae[1];
-      // targets 2 lane + s and 2 lane + 1 + s
-      atomicAdd(&e2up[128 * (s & 1) + lane + (s >> 1)], r0);
-      atomicAdd(&e2up[128 * ((s + 1) & 1) + lane + ((s + 1) >> 1)], r1);
+      atomicAdd(&e2up[128 * (s & 1) + lane + (s >> 1)], r0 + r1);
     }
   }
   // downward spreading, Kabal (28): E2[i-1] = aLe E2[i] + Ene[i-1]  (suffix scan)
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
   const double* pw_ref = lds + kOffPw;
   double* pw_test = lds + kUnitDoubles + kOffPw;
   double* dlog = lds + kOffScratch;                          // [512] shared: ln(Pw_test / Pw_ref)
-  double* cbuf = lds + kUnitDoubles + kOffScratch;           // [256] shared: correlation by lag
+  double* cbuf = lds + kUnitDoubles + kOffScratch;           // [2][256] shared: correlation by lag, per k half
 
   // ---- error harmonic structure, part 1 (movs.c:1383-1391): both waves, 256 bins each ----
 #pragma unroll
@@ -451,24 +451,37 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
   }
   __syncthreads();
   // ---- part 2: c[l] = sum_{k<256} d[k] d[k+l]  (the reference evaluates the same sums through
-  // 512-point FFTs, movs.c:1279-1315).  Each wave takes 128 lags, a lane the lag pair
-  // (l0, l0+1) with l0 even; two k per step so that every LDS read is an aligned 16-byte one.
+  // 512-point FFTs, movs.c:1279-1315).  Each wave takes half of the k range for all 256 lags; a
+  // lane owns four consecutive lags and walks k in steps of four: a 4 x 4 register tile, 16 FMAs
+  // per two broadcast and two streaming 16-byte LDS reads.  The halves are added in part 3.
   {
-    const int l0 = 128 * sig + 2 * lane;
-    double c0 = 0., c1 = 0.;
-    double2 w = *reinterpret_cast<const double2*>(dlog + l0);          // d[k+l0], d[k+l0+1] at k = 0
-#pragma unroll 8
-    for (int k = 0; k < 256; k += 2) {
-      const double2 dk = *reinterpret_cast<const double2*>(dlog + k);  // broadcast
-      // next window; the very last one of lag pair (254,255) would start at index 512: unused, clamped
-      const double2 wn = *reinterpret_cast<const double2*>(dlog + min(k + 2 + l0, 510));
-      c0 = fma(dk.x, w.x, c0);
-      c1 = fma(dk.x, w.y, c1);
-      c0 = fma(dk.y, w.y, c0);
-      c1 = fma(dk.y, wn.x, c1);
-      w = wn;
+    const int l0 = 4 * lane;
+    const int k0 = 128 * sig;
+    double c[4] = {0., 0., 0., 0.};
+    double w[8];
+    {
+      const double2 a = *reinterpret_cast<const double2*>(dlog + k0 + l0);
+      const double2 b = *reinterpret_cast<const double2*>(dlog + k0 + l0 + 2);
+      w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
     }
-    *reinterpret_cast<double2*>(cbuf + l0) = make_double2(c0, c1);
+#pragma unroll 4
+    for (int k = k0; k < k0 + 128; k += 4) {
+      const double2 d01 = *reinterpret_cast<const double2*>(dlog + k);        // broadcast
+      const double2 d23 = *reinterpret_cast<const double2*>(dlog + k + 2);
+      const double2 a = *reinterpret_cast<const double2*>(dlog + k + l0 + 4);
+      const double2 b = *reinterpret_cast<const double2*>(dlog + k + l0 + 6);  // [.. + 7] <= 511
+      w[4] = a.x; w[5] = a.y; w[6] = b.x; w[7] = b.y;
+      const double dk[4] = {d01.x, d01.y, d23.x, d23.y};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = fma(dk[i], w[i + j], c[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = w[4 + i];
+    }
+    double2* out = reinterpret_cast<double2*>(cbuf + 256 * sig + l0);
+    out[0] = make_double2(c[0], c[1]);
+    out[1] = make_double2(c[2], c[3]);
   }
   __syncthreads();
 
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     double* d = dlog;
     double c[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) c[m] = cbuf[lane + 64 * m];
+    for (int m = 0; m < 4; ++m) c[m] = cbuf[lane + 64 * m] + cbuf[256 + lane + 64 * m];
     const double d0 = __shfl(c[0], 0, 64);
     // running window energy dk[l] = d0 + sum_{j<l} (d[j+256]^2 - d[j]^2)   (:1413-1418)
     {
