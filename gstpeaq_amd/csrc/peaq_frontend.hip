@@ -201,28 +201,39 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
   return base + slot;
 }
 
+// One frame of one signal: `p` points at the frame's first sample (channel 0), `left` samples
+// of the signal remain from there on.  Both are wave-uniform, all lane arithmetic is 32-bit.
 struct FrameSrc {
-  const float* x;
-  long long s0, n_valid;
+  const float* p;
+  int left;                                          // may be <= 0 or > 2048
   int channels, chan;
   bool whole;
   // samples 2n and 2n+1 of the frame
   __device__ __forceinline__ void load2(int n, float& x0, float& x1) const {
     if (whole) {
       if (channels == 1) {
-        const float2 v = *reinterpret_cast<const float2*>(x + s0 + 2 * n);
+        const float2 v = reinterpret_cast<const float2*>(p)[n];
         x0 = v.x;
         x1 = v.y;
       } else {
-        const float4 v = *reinterpret_cast<const float4*>(x + (s0 + 2 * n) * 2);
+        const float4 v = reinterpret_cast<const float4*>(p)[n];
         x0 = chan ? v.y : v.x;
         x1 = chan ? v.w : v.z;
       }
     } else {                                         // zero-padded flush frame (gstpeaq.c:733-738)
-      const long long i0 = s0 + 2 * n, i1 = i0 + 1;
-      x0 = i0 < n_valid ? x[i0 * channels + chan] : 0.f;
-      x1 = i1 < n_valid ? x[i1 * channels + chan] : 0.f;
+      const int i0 = 2 * n, i1 = i0 + 1;
+      x0 = i0 < left ? p[i0 * channels + chan] : 0.f;
+      x1 = i1 < left ? p[i1 * channels + chan] : 0.f;
     }
+  }
+  __device__ __forceinline__ void set(const float* x, long long s0, long long n_valid, int channels_, int chan_) {
+    channels = channels_;
+    chan = chan_;
+    p = x + s0 * channels;
+    const long long l = n_valid - s0;
+    left = l < 0 ? 0 : l > kFrame ? kFrame : (int)l;
+    // vector loads need the whole frame in range and a 8 B (mono) / 16 B (stereo) aligned start
+    whole = left == kFrame && (reinterpret_cast<size_t>(p) & (channels == 1 ? 7 : 15)) == 0;
   }
 };
 
@@ -257,20 +268,11 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
   }
   const size_t pair_off = (size_t)pair * a.pair_stride * a.channels;
   FrameSrc src_ref, src_test;
-  src_ref.x = a.ref + pair_off;
-  src_test.x = a.test + pair_off;
-  src_ref.s0 = (long long)(frame - frame_origin) * kHop + a.off_ref;
-  src_test.s0 = (long long)(frame - frame_origin) * kHop + a.off_test;
-  src_ref.n_valid = (long long)n_ref;
-  src_test.n_valid = (long long)n_test;
-  src_ref.channels = src_test.channels = a.channels;
-  src_ref.chan = src_test.chan = chan;
-  // vector loads need the whole frame in range and a 8 B (mono) / 16 B (stereo) aligned start
-  const size_t amask = a.channels == 1 ? 7 : 15;
-  src_ref.whole = src_ref.s0 + kFrame <= src_ref.n_valid &&
-                  ((reinterpret_cast<size_t>(src_ref.x + src_ref.s0 * a.channels) & amask) == 0);
-  src_test.whole = src_test.s0 + kFrame <= src_test.n_valid &&
-                   ((reinterpret_cast<size_t>(src_test.x + src_test.s0 * a.channels) & amask) == 0);
+  {
+    const long long s0 = (long long)(frame - frame_origin) * kHop;
+    src_ref.set(a.ref + pair_off, s0 + a.off_ref, (long long)n_ref, a.channels, chan);
+    src_test.set(a.test + pair_off, s0 + a.off_test, (long long)n_test, a.channels, chan);
+  }
   const FrameSrc& src = sig ? src_test : src_ref;
   double* __restrict__ rec =
       a.records + ((size_t)(pair * a.frames_per_launch + fl) * a.channels + chan) * kRecDoubles;
