@@ -32,6 +32,8 @@
 
 #include "peaq_device.h"
 #include "peaq_kernels.h"
+#include <type_traits>
+
 #include "peaq_wave.h"
 
 namespace peaq {
@@ -201,6 +203,14 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
   return base + slot;
 }
 
+// a wave-uniform pointer, pinned to scalar registers (loads then take the base + 32-bit lane offset form)
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+
 // One frame of one signal: `p` points at the frame's first sample (channel 0), `left` samples
 // of the signal remain from there on.  Both are wave-uniform, all lane arithmetic is 32-bit.
 struct FrameSrc {
@@ -208,9 +218,10 @@ struct FrameSrc {
   int left;                                          // may be <= 0 or > 2048
   int channels, chan;
   bool whole;
-  // samples 2n and 2n+1 of the frame
+  // samples 2n and 2n+1 of the frame; WHOLE: all 2048 samples exist and the start is aligned
+  template <bool WHOLE>
   __device__ __forceinline__ void load2(int n, float& x0, float& x1) const {
-    if (whole) {
+    if (WHOLE) {
       if (channels == 1) {
         const float2 v = reinterpret_cast<const float2*>(p)[n];
         x0 = v.x;
@@ -229,7 +240,7 @@ struct FrameSrc {
   __device__ __forceinline__ void set(const float* x, long long s0, long long n_valid, int channels_, int chan_) {
     channels = channels_;
     chan = chan_;
-    p = x + s0 * channels;
+    p = uniform_ptr(x + s0 * channels);
     const long long l = n_valid - s0;
     left = l < 0 ? 0 : l > kFrame ? kFrame : (int)l;
     // vector loads need the whole frame in range and a 8 B (mono) / 16 B (stereo) aligned start
@@ -281,20 +292,26 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
   cplx z[16];
   float amax = 0.f;
   double energy = 0.;
+  auto load_frame = [&](auto whole) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int n = lane + 64 * r;
-    float x0, x1;
-    src.load2(n, x0, x1);
-    z[r] = {ct->hann[2 * n] * (double)x0, ct->hann[2 * n + 1] * (double)x1};
-    if (r >= 8) {                                    // samples 1024..2047; float products, double sum
-      energy += (double)(x0 * x0);
-      energy += (double)(x1 * x1);
+    for (int r = 0; r < 16; ++r) {
+      const int n = lane + 64 * r;
+      float x0, x1;
+      src.template load2<decltype(whole)::value>(n, x0, x1);
+      z[r] = {ct->hann[2 * n] * (double)x0, ct->hann[2 * n + 1] * (double)x1};
+      if (r >= 8) {                                  // samples 1024..2047; float products, double sum
+        energy += (double)(x0 * x0);
+        energy += (double)(x1 * x1);
+      }
+      // a single sample above the threshold settles the boundary detector; sample 0
+      // is excluded because the first tested window is [1..5]
+      amax = fmaxf(amax, n == 0 ? fabsf(x1) : fmaxf(fabsf(x0), fabsf(x1)));
     }
-    // a single sample above the threshold settles the boundary detector; sample 0
-    // is excluded because the first tested window is [1..5]
-    amax = fmaxf(amax, n == 0 ? fabsf(x1) : fmaxf(fabsf(x0), fabsf(x1)));
-  }
+  };
+  if (src.whole)                                     // one uniform branch, not one per sample
+    load_frame(std::true_type{});
+  else
+    load_frame(std::false_type{});
   energy = wave_sum(energy);
   const int energy_flag = energy >= 8000. / (32768. * 32768.);
 
@@ -312,7 +329,7 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int n = lane_q + 64 * r;
         float x0, x1;
-        src.load2(n, x0, x1);
+        src.template load2<false>(n, x0, x1);        // rare path: the guarded loads serve both cases
         reinterpret_cast<float2*>(ax)[n] = make_float2(fabsf(x0), fabsf(x1));
       }
       wave_lds_fence();
@@ -507,17 +524,23 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     double se = 0., ne = 0.;
     int lane_q = lane;                               // opaque copy, see above
     asm volatile("" : "+v"(lane_q));
+    auto hop_energy = [&](auto whole) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int n = lane_q + 64 * r;
-      float r0, r1, t0, t1;
-      src_ref.load2(n, r0, r1);
-      src_test.load2(n, t0, t1);
-      se += (double)(r0 * r0);
-      se += (double)(r1 * r1);
-      ne += (double)((r0 - t0) * (r0 - t0));
-      ne += (double)((r1 - t1) * (r1 - t1));
-    }
+      for (int r = 0; r < 8; ++r) {
+        const int n = lane_q + 64 * r;
+        float r0, r1, t0, t1;
+        src_ref.template load2<decltype(whole)::value>(n, r0, r1);
+        src_test.template load2<decltype(whole)::value>(n, t0, t1);
+        se += (double)(r0 * r0);
+        se += (double)(r1 * r1);
+        ne += (double)((r0 - t0) * (r0 - t0));
+        ne += (double)((r1 - t1) * (r1 - t1));
+      }
+    };
+    if (src_ref.whole && src_test.whole)
+      hop_energy(std::true_type{});
+    else
+      hop_energy(std::false_type{});
     se = wave_sum(se);
     ne = wave_sum(ne);
     if (lane == 0) {
