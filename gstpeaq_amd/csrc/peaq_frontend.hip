@@ -387,13 +387,23 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
   // All lanes of one atomic hit the same parity at consecutive idx (8-byte stride): no bank conflicts.
   double* e2up = scratch;                            // [2][128]
   for (int i = lane; i < 256; i += 64) e2up[i] = 0.;
+  // Band sums with a balanced assignment -- lane L adds up band L (narrow) and band NB-1-L (wide):
+  // the longest loop is ~27 bins instead of the ~50 of two adjacent top bands -- handed over to
+  // the two-adjacent-bands layout of everything that follows through LDS.
+  double* ppx = scratch + 256;                       // [NB]
+  if (lane < (NB + 1) / 2) {
+    const int b1 = lane, b2 = NB - 1 - lane;
+    ppx[b1] = group_band(bt, b1, [&](int k) { return pw[k]; });
+    if (b2 != b1) ppx[b2] = group_band(bt, b2, [&](int k) { return pw[k]; });
+  }
+  wave_lds_fence();
   double ene[2], ae[2];
   const int b0 = 2 * lane;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int b = b0 + s;
     if (b < NB) {
-      const double pp = group_band(bt, b, [&](int k) { return pw[k]; }) + bt->internal_noise[b];   // :483-485
+      const double pp = ppx[b] + bt->internal_noise[b];                                            // :483-485
       // Kabal (23)-(24); fftearmodel.c:649-656.  a^y evaluated as exp(y ln a).
       const double ln_a = bt->ln_aUC[b] + bt->dz02 * log(pp);
       const double a_uce = exp(ln_a);
@@ -513,13 +523,13 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
       pw_test[k] = r - 2 * sqrt(r * t) + t;
     }
     wave_lds_fence();
-    double nib[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int b = b0 + s;
-      nib[s] = b < NB ? group_band(bt, b, [&](int k) { return pw_test[k]; }) : 0.;
+    if (lane < (NB + 1) / 2) {                        // balanced assignment as above, straight to the record
+      const int b1 = lane, b2 = NB - 1 - lane;
+      rec[kRecNoise + b1] = group_band(bt, b1, [&](int k) { return pw_test[k]; });
+      if (b2 != b1) rec[kRecNoise + b2] = group_band(bt, b2, [&](int k) { return pw_test[k]; });
+    } else if (lane < (NB + 1) / 2 + kBandStride - NB) {
+      rec[kRecNoise + NB + lane - (NB + 1) / 2] = 0.;  // padding slots of the band vector
     }
-    if (b0 < kBandStride) *reinterpret_cast<double2*>(rec + kRecNoise + b0) = make_double2(nib[0], nib[1]);
     // ---- totalsnr energies over the hop (gstpeaq.c:913-918; float products) --------
     double se = 0., ne = 0.;
     int lane_q = lane;                               // opaque copy, see above
