@@ -109,9 +109,10 @@ struct peaq_ctx {
   FbTables* d_fb = nullptr;
   std::mutex mu;            // serialises batch calls / workspace use
   // batch workspace
-  DevBuf records, records2, fb_records, state, fbstate, hp_scratch, counts;
+  DevBuf records, records2, fb_records, fb_records2, state, fbstate, hp_scratch, hp_scratch2, counts;
   hipStream_t aux = nullptr;   // the back end runs here, overlapped with the next chunk's front end
   hipStream_t aux2 = nullptr;  // advanced: the filter-bank path runs here, beside the FFT path
+  hipStream_t aux3 = nullptr, aux4 = nullptr;   // ... its high-pass stage and its back end (3-stage pipeline)
   hipEvent_t batch_begin = nullptr, batch_end = nullptr;
   bool batch_pending = false;
   std::vector<TimedSpan> spans;
@@ -170,6 +171,8 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
     HIP_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
   }
   HIP_TRY(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&c->aux3, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&c->aux4, hipStreamNonBlocking));
   *out = c;
   return PEAQ_OK;
 }
@@ -187,6 +190,10 @@ extern "C" void peaq_ctx_destroy(peaq_ctx* c) {
   c->records2.release();
   if (c->aux) (void)hipStreamDestroy(c->aux);
   if (c->aux2) (void)hipStreamDestroy(c->aux2);
+  if (c->aux3) (void)hipStreamDestroy(c->aux3);
+  if (c->aux4) (void)hipStreamDestroy(c->aux4);
+  c->fb_records2.release();
+  c->hp_scratch2.release();
   c->fb_records.release();
   c->state.release();
   c->fbstate.release();
@@ -223,8 +230,10 @@ extern "C" size_t peaq_batch_workspace_bytes(int advanced, int channels, int n_p
              (size_t)n_pairs * 4 * sizeof(uint32_t);
   if (advanced) {
     const unsigned bc = kFbBlocksPerChunk;
-    b += (size_t)n_pairs * bc * channels * kFbRecDoubles * sizeof(double);
-    b += (size_t)n_pairs * channels * 2 * (sizeof(FbSignalState) + ((size_t)bc * kFbFrame + kFbRing) * sizeof(double));
+    const size_t nbuf = count_frames(n_max, n_max, kFbFrame, kFbFrame) > bc ? 2 : 1;   // pipelined: double buffers
+    b += nbuf * (size_t)n_pairs * bc * channels * kFbRecDoubles * sizeof(double);
+    b += (size_t)n_pairs * channels * 2 *
+         (sizeof(FbSignalState) + nbuf * ((size_t)bc * kFbFrame + kFbRing) * sizeof(double));
   }
   return b;
 }
@@ -237,8 +246,13 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
     const unsigned n_signals = (unsigned)n_pairs * channels * 2;
     const unsigned bc = std::min<unsigned>(kFbBlocksPerChunk, (max_blocks + 9) / 10 * 10);
     const size_t row_stride = (size_t)kFbRing + (size_t)bc * kFbFrame;
+    const bool piped = max_blocks > bc;               // more than one chunk: 3-stage pipeline, double buffers
     HIP_TRY(c->hp_scratch.reserve((size_t)n_signals * row_stride * sizeof(double)));
     HIP_TRY(c->fb_records.reserve((size_t)n_pairs * bc * channels * kFbRecDoubles * sizeof(double)));
+    if (piped) {
+      HIP_TRY(c->hp_scratch2.reserve((size_t)n_signals * row_stride * sizeof(double)));
+      HIP_TRY(c->fb_records2.reserve((size_t)n_pairs * bc * channels * kFbRecDoubles * sizeof(double)));
+    }
     HIP_TRY(c->fbstate.reserve((size_t)n_signals * sizeof(FbSignalState)));
     HIP_TRY(hipMemsetAsync(c->fbstate.p, 0, (size_t)n_signals * sizeof(FbSignalState), stream));
     FbFrontArgs ff{};
@@ -256,34 +270,68 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
     ff.bands = c->d_bands40;
     ff.fb = c->d_fb;
     ff.fbstate = c->fbstate.as<FbSignalState>();
-    ff.hp_scratch = c->hp_scratch.as<double>();
     ff.hp_row_stride = row_stride;
-    ff.records = c->fb_records.as<double>();
     FbBackendArgs fbk{};
-    fbk.records = ff.records;
     fbk.n_blocks = d_nblocks;
     fbk.n_blocks_uniform = max_blocks;
     fbk.channels = channels;
     fbk.bands = c->d_bands40;
     fbk.state = c->state.as<PairState>();
-    unsigned prev = 0;
-    for (uint32_t b0 = 0; b0 < max_blocks; b0 += bc) {
+    // Three stages per chunk of blocks, each on its own stream: the high-pass filter (a few hundred
+    // waves, latency bound), the filter bank (the bulk), the back end (one workgroup per pair).
+    // Stage s of chunk i runs beside stage s+1 of chunk i-1; rows and records are double buffered.
+    hipStream_t s_hp = piped ? c->aux3 : stream, s_bank = stream, s_be = piped ? c->aux4 : stream;
+    if (piped) {
+      hipEvent_t ready = c->next_event();
+      if (!ready) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
+      HIP_TRY(hipEventRecord(ready, stream));          // state initialised, filter state cleared
+      HIP_TRY(hipStreamWaitEvent(s_hp, ready, 0));
+      HIP_TRY(hipStreamWaitEvent(s_be, ready, 0));
+    }
+    double* rows[2] = {c->hp_scratch.as<double>(), piped ? c->hp_scratch2.as<double>() : c->hp_scratch.as<double>()};
+    double* recs[2] = {c->fb_records.as<double>(), piped ? c->fb_records2.as<double>() : c->fb_records.as<double>()};
+    hipEvent_t bank_done[2] = {nullptr, nullptr}, be_done[2] = {nullptr, nullptr};
+    unsigned prev = 0, chunk = 0;
+    for (uint32_t b0 = 0; b0 < max_blocks; b0 += bc, ++chunk) {
       const unsigned nb = std::min<uint32_t>(bc, max_blocks - b0);
+      const int b = chunk & 1;
       ff.block0 = b0;
       ff.blocks_per_launch = nb;
       ff.prev_blocks = prev;
       ff.first_launch = b0 == 0;
+      ff.hp_scratch = rows[b];
+      ff.hp_prev = chunk ? rows[b ^ 1] : nullptr;
+      ff.records = recs[b];
+      fbk.records = recs[b];
       fbk.block0 = b0;
       fbk.blocks_per_launch = nb;
-      hipEvent_t e0 = c->next_event(), e1 = c->next_event();
-      if (!e0 || !e1) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
-      HIP_TRY(hipEventRecord(e0, stream));
-      HIP_TRY(launch_fb_frontend(ff, n_pairs, stream));
-      HIP_TRY(launch_fb_backend(fbk, n_pairs, stream));
-      HIP_TRY(hipEventRecord(e1, stream));
+      hipEvent_t e0 = c->next_event(), e1 = c->next_event(), e_hp = c->next_event(), e_be = c->next_event();
+      if (!e0 || !e1 || !e_hp || !e_be) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
+      if (piped) {
+        if (bank_done[b]) HIP_TRY(hipStreamWaitEvent(s_hp, bank_done[b], 0));   // rows[b] no longer read
+        if (be_done[b]) HIP_TRY(hipStreamWaitEvent(s_hp, be_done[b], 0));       // recs[b] no longer read
+      }
+      HIP_TRY(launch_fb_hp(ff, n_pairs, s_hp));
+      if (piped) {
+        HIP_TRY(hipEventRecord(e_hp, s_hp));
+        HIP_TRY(hipStreamWaitEvent(s_bank, e_hp, 0));
+      }
+      HIP_TRY(hipEventRecord(e0, s_bank));
+      HIP_TRY(launch_fb_bank(ff, n_pairs, s_bank));
+      HIP_TRY(hipEventRecord(e1, s_bank));
+      bank_done[b] = e1;
+      if (piped) HIP_TRY(hipStreamWaitEvent(s_be, e1, 0));
+      HIP_TRY(launch_fb_backend(fbk, n_pairs, s_be));
+      if (piped) {
+        HIP_TRY(hipEventRecord(e_be, s_be));
+        be_done[b] = e_be;
+      }
       c->spans.push_back({e0, e1, 2});
       prev = nb;
     }
+    if (piped)
+      for (int i = 0; i < 2; ++i)
+        if (be_done[i]) HIP_TRY(hipStreamWaitEvent(stream, be_done[i], 0));    // join: `stream` ends the path
   return PEAQ_OK;
 }
 

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
       for (int i = 0; i < kFbRing; ++i) my_row[i] = 0.;
     } else {
       const size_t tail = (size_t)a.prev_blocks * kFbFrame;
-      for (int i = 0; i < kFbRing; ++i) my_row[i] = my_row[tail + i];
+      const double* __restrict__ prev_row = a.hp_prev ? a.hp_prev + (size_t)gg * row_len : my_row;
+      for (int i = 0; i < kFbRing; ++i) my_row[i] = prev_row[tail + i];
     }
   }
   HpWalk w{st->hp[0], st->hp[1], st->hp[2], st->hp[3], st->hp[4], st->hp[5]};
@@ -522,14 +523,23 @@ __global__ __launch_bounds__(256, 3) void fb_bank_kernel(FbFrontArgs a, unsigned
   }
 }
 
-hipError_t launch_fb_frontend(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream) {
+hipError_t launch_fb_hp(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream) {
   const unsigned n_signals = n_pairs * a.channels * 2;
   if (n_signals == 0 || a.blocks_per_launch == 0) return hipSuccess;
   hipLaunchKernelGGL(fb_hp_kernel, dim3((n_signals + 63) / 64), dim3(64), 0, stream, a, n_signals);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  return hipGetLastError();
+}
+
+hipError_t launch_fb_bank(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream) {
+  const unsigned n_signals = n_pairs * a.channels * 2;
+  if (n_signals == 0 || a.blocks_per_launch == 0) return hipSuccess;
   hipLaunchKernelGGL(fb_bank_kernel, dim3(n_signals), dim3(256), 0, stream, a, n_signals);
   return hipGetLastError();
+}
+
+hipError_t launch_fb_frontend(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream) {
+  const hipError_t e = launch_fb_hp(a, n_pairs, stream);
+  return e != hipSuccess ? e : launch_fb_bank(a, n_pairs, stream);
 }
 
 }  // namespace peaq

@@ -85,10 +85,13 @@ struct FbFrontArgs {
   const FbTables* fb;
   FbSignalState* fbstate;       // [pair][channel][2]
   double* hp_scratch;           // rows [signal][hp_row_stride]: 1456 history + filtered samples of the launch
+  const double* hp_prev;        // rows of the previous launch (history source); nullptr: hp_scratch itself
   size_t hp_row_stride;
   double* records;              // [pair][block - block0][channel][kFbRecDoubles]
 };
-hipError_t launch_fb_frontend(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream);
+hipError_t launch_fb_frontend(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream);   // high-pass + filter bank
+hipError_t launch_fb_hp(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream);
+hipError_t launch_fb_bank(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream);
 
 struct FbBackendArgs {
   const double* records;
