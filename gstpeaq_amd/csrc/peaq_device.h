@@ -19,6 +19,17 @@ constexpr int kFbFrame    = 192;    // fbearmodel.c:48
 constexpr int kFbBands    = 40;
 constexpr int kFbRing     = 1456;   // fbearmodel.c:52
 constexpr int kFbTaps     = 11;     // backward-masking FIR history (fbearmodel.c:262)
+// Filter bank on the matrix cores.  All 40 filters are centred on the same delay
+// (D + N/2 = 729 samples) and h(N - n) = conj(h(n)), so the bank is two GEMMs over the delays
+// d = 1..729 only: the real parts against x[t-d] + x[t-(1458-d)], the imaginary parts against
+// x[t-d] - x[t-(1458-d)].  3 row tiles of 16 bands (longest first); first delay, K steps (4 delays
+// each) and offset (in K steps) of every tile in FbTables::mf_re / mf_im.
+constexpr int kFbCentre = 729;
+constexpr int kMfTiles = 3;
+constexpr int kMfD0[kMfTiles]    = {2, 470, 677};
+constexpr int kMfSteps[kMfTiles] = {182, 65, 14};
+constexpr int kMfBase[kMfTiles]  = {0, 182, 247};
+constexpr int kMfTotalSteps = 261;
 
 // ---- constant tables (built on the host in FP64, peaq_tables.cpp) ----------
 struct CommonTables {
@@ -62,6 +73,10 @@ struct FbTables {               // fbearmodel.c:57-61,182-225
   double h_re[12000];           // sum(N/2+1) = 10954 coefficients
   double h_im[12000];
   double h_ri[24000];           // the same, interleaved {re, im} per tap (one 16-byte load per tap)
+  // A operands of the two GEMMs (see kMf* above): step s of tile r, lane = band_in_tile + 16 (d - d0 - 4 s);
+  // the centre tap carries half its weight (its two "mirror" samples coincide)
+  double mf_re[kMfTotalSteps * 64];
+  double mf_im[kMfTotalSteps * 64];
 };
 
 // ---- per-frame record: front end -> back end --------------------------------

@@ -188,167 +188,158 @@ constexpr int kACols = 64;                          // A[band][time] row stride
 __host__ __device__ constexpr int win_off(int u) { return (u & 31) * kWinRow + (u >> 5); }
 
 struct BankLds {
-  union {
-    double win[32 * kWinRow];                       // phase 1
-    struct {
-      double re[kFbBands][kACols];                  // phases 2..4: A[band][time]
-      double im[kFbBands][kACols];
-    } a;
-  };
+  double win[32 * kWinRow];                         // phase 1: the filtered signal, B operand of the GEMM
+  struct {
+    double re[kFbBands][kACols];                    // A[band][time]: GEMM result, then phases 2..4 in place
+    double im[kFbBands][kACols];
+  } a;
   double e1[kFbBands][kTileBlocks];
   double hist[kFbBands][10];       // the 10 newest E0 values of the previous tile, oldest first
   double cu[kFbBands];
 };
 
-// One band's complex FIR at this lane's time point (fbearmodel.c:404-434).
-// win_t = window + t.  Taps are consumed in groups of 8; all LDS offsets inside a 32-tap
-// macro step are compile-time constants.  Software pipeline: while group G is evaluated
-// (16 LDS reads, 16 add/sub, 16 fma) the 8 coefficient pairs of group G+1 are requested
-// through the SCALAR cache (the address is wave-uniform; v_fma_f64 takes the coefficient
-// straight from an SGPR pair).  Broadcast loads through the vector memory pipe cost a full
-// 64-lane transaction each and saturated the texture addresser (measured: 1.4e9 VMEM
-// instructions per launch = the whole kernel time).
 // A plain ds_read_b64 moves 256 B/clk/CU, the merged ds_read2_b64 the compiler likes to form
-// only 128 (MI355X_MICROARCH.md, LDS table): read the window through volatile accesses so that
-// every sample is its own ds_read_b64 with an immediate offset.
+// only 128 (MI355X_MICROARCH.md, LDS table): volatile accesses keep every read its own ds_read_b64.
 __device__ __forceinline__ double lds_rd(const double* p) {
   return *(const volatile __attribute__((address_space(3))) double*)p;
 }
 
-typedef double v2d __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(4))) v2d* gcoef_t;
+// ---------------------------------------------------------------------------
+// Phase 1, the 40 complex FIR filters (fbearmodel.c:399-435), on the matrix cores.
+// For the 60 time points of a tile (one every 32 samples) the bank is a pair of GEMMs over the
+// delays d = 2..729 (peaq_device.h, kMf*):
+//   re[b][t] = sum_d Hre[b][d] (x[32t - d] + x[32t - (1458 - d)])
+//   im[b][t] = sum_d Him[b][d] (x[32t - d] - x[32t - (1458 - d)])
+// v_mfma_f64_16x16x4_f64: 16 bands x 16 time points x 4 delays per instruction, the B operands
+// built on the fly from two LDS reads of the window.  A wave keeps eight accumulator tiles
+// (64 time points x {re, im}) so that every coefficient fetch (two coalesced 512-byte reads
+// through L2 per K step) feeds eight MFMAs.  The 261 K steps of the three row tiles are cut
+// into four runs, one per wave; a run that ends inside a row tile leaves a partial sum, so all
+// runs are added into A with LDS atomics (A is zeroed in phase 0).  FP64 MFMA has the rate of
+// the FP64 vector pipe, but it issues once per 64 cycles instead of once per 4: the pipe is
+// actually kept full and the VALU stays free for the operand construction.
+// ---------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
 
-template <int B>
-__device__ __forceinline__ void fir_band(const double* __restrict__ win_t, const double2* __restrict__ coef,
-                                         double& re_out, double& im_out) {
-  constexpr int N = kLen[B];
-  constexpr int D = 1 + (kLen[0] - N) / 2;           // (31) in BS.1387
-  constexpr int H = N / 2;
-  constexpr int U1 = kFbRing - D;                    // x1(n): u = U1 - n   (delay D + n)
-  constexpr int U2 = kFbRing - D - N;                // x2(n): u = U2 + n   (delay D + N - n)
-  constexpr int FULL = (H - 1) / 32;
-  constexpr int REM = (H - 1) - 32 * FULL;
-  constexpr int REMG = (REM + 7) / 8;                // groups in the remainder
-  gcoef_t hc = (gcoef_t)(coef + coef_offset(B));
-  double re = 0., im = 0.;
-  // GROUP_FENCE makes the next loads depend on the accumulators: without it the compiler
-  // hoists the loads of a whole filter to the top and spills them.
-#define GROUP_FENCE(ptr) asm volatile("" : "+s"(ptr), "+v"(re), "+v"(im))
-  v2d cc[8], cn[8];
-  {
-    gcoef_t c0 = hc + 1;
-    GROUP_FENCE(c0);
+__device__ __forceinline__ void fir_mfma(BankLds& sh, const double* __restrict__ mf_re,
+                                         const double* __restrict__ mf_im, int wv, int lane) {
+  const int j = lane & 15, kk = lane >> 4;
+  // K steps [g, g_end) of this wave: 66 + 65 + 65 + 65
+  int g = wv == 0 ? 0 : 1 + 65 * wv;
+  const int g_end = 66 + 65 * wv;
+  static_assert(66 + 65 * 3 == kMfTotalSteps, "split of the K steps over the four waves");
+  while (g < g_end) {
+    const int r = g >= kMfBase[2] ? 2 : g >= kMfBase[1] ? 1 : 0;
+    const int base = r == 2 ? kMfBase[2] : r == 1 ? kMfBase[1] : 0;
+    const int steps = r == 2 ? kMfSteps[2] : r == 1 ? kMfSteps[1] : kMfSteps[0];
+    const int d0 = r == 2 ? kMfD0[2] : r == 1 ? kMfD0[1] : kMfD0[0];
+    const int s0 = g - base;
+    const int n = min(steps - s0, g_end - g);        // K steps of this segment
+    const v4d zero = {0., 0., 0., 0.};
+    v4d ar0 = zero, ar1 = zero, ar2 = zero, ar3 = zero, ai0 = zero, ai1 = zero, ai2 = zero, ai3 = zero;
+    const double* __restrict__ cr = mf_re + (size_t)g * 64 + lane;
+    const double* __restrict__ ci = mf_im + (size_t)g * 64 + lane;
+    const int d = d0 + 4 * s0 + kk;                  // this lane's delay in the first K step
+    int u1 = kFbRing - d;                            // window coordinate of x[-d] at t = 0 ...
+    int u2 = d - 2;                                  // ... and of its mirror x[-(1458 - d)]
+    auto step = [&](double hr, double hi) {
+      const double* p1 = sh.win + win_off(u1) + j;   // time points j, 16 + j, 32 + j, 48 + j
+      const double* p2 = sh.win + win_off(u2) + j;
+      const double x0 = lds_rd(p1), x1 = lds_rd(p1 + 16), x2 = lds_rd(p1 + 32), x3 = lds_rd(p1 + 48);
+      const double y0 = lds_rd(p2), y1 = lds_rd(p2 + 16), y2 = lds_rd(p2 + 32), y3 = lds_rd(p2 + 48);
+      ar0 = __builtin_amdgcn_mfma_f64_16x16x4f64(hr, x0 + y0, ar0, 0, 0, 0);
+      ai0 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, x0 - y0, ai0, 0, 0, 0);
+      ar1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hr, x1 + y1, ar1, 0, 0, 0);
+      ai1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, x1 - y1, ai1, 0, 0, 0);
+      ar2 = __builtin_amdgcn_mfma_f64_16x16x4f64(hr, x2 + y2, ar2, 0, 0, 0);
+      ai2 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, x2 - y2, ai2, 0, 0, 0);
+      ar3 = __builtin_amdgcn_mfma_f64_16x16x4f64(hr, x3 + y3, ar3, 0, 0, 0);
+      ai3 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, x3 - y3, ai3, 0, 0, 0);
+      u1 -= 4;
+      u2 += 4;
+    };
+    // coefficients are requested four K steps (2048 MFMA cycles) ahead of their use
+    int s = 0;
+    double nr[4], ni[4];
+    if (n >= 4) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) cc[j] = (FULL > 0 || j < REM) ? c0[j] : v2d{0., 0.};
-  }
-#pragma unroll 1
-  for (int q = 0; q < FULL; ++q) {
-    // n = 1 + 32 q + r: moving 32 taps on shifts the column by one, the row pattern repeats
-    const double* p1 = win_t - q;
-    const double* p2 = win_t + q;
-    gcoef_t c = hc + 1 + 32 * q;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      GROUP_FENCE(c);
-      // coefficients of the NEXT group (the first group of the remainder after the last macro step)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int rn = 8 * (g + 1) + j;
-        cn[j] = (g < 3 || q + 1 < FULL || j < REM) ? c[rn] : v2d{0., 0.};   // c[32..39]: next macro step / remainder
+      for (int q = 0; q < 4; ++q) {
+        nr[q] = cr[64 * q];
+        ni[q] = ci[64 * q];
       }
-      double a[8], b[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = 8 * g + j;
-        a[j] = lds_rd(p1 + win_off(U1 - 1 - r));
-        // the reference's doubled ring buffer makes band 0's delay-1456 tap (n = 1) read the
-        // NEWEST sample (fb_buf[offset + 1456] aliases fb_buf[offset]); reproduced
-        b[j] = (B == 0 && r == 0) ? (q == 0 ? lds_rd(win_t + win_off(kFbRing)) : lds_rd(p2 + win_off(U2 + 1 + r)))
-                                  : lds_rd(p2 + win_off(U2 + 1 + r));
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        re = fma(a[j] + b[j], cc[j].x, re);          // even symmetry
-        im = fma(a[j] - b[j], cc[j].y, im);          // odd symmetry
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) cc[j] = cn[j];
     }
-  }
-  if (REM > 0) {
-    const double* p1 = win_t - FULL;
-    const double* p2 = win_t + FULL;
-    gcoef_t c = hc + 1 + 32 * FULL;
+    for (; s + 4 <= n; s += 4) {
+      double kr[4], ki[4];
 #pragma unroll
-    for (int g = 0; g < REMG; ++g) {
-      GROUP_FENCE(c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int rn = 8 * (g + 1) + j;
-        if (g + 1 < REMG) cn[j] = rn < REM ? c[rn] : v2d{0., 0.};
+      for (int q = 0; q < 4; ++q) {
+        kr[q] = nr[q];
+        ki[q] = ni[q];
       }
-      double a[8], b[8];
+      if (s + 8 <= n) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = 8 * g + j;
-        if (r < REM) {
-          a[j] = lds_rd(p1 + win_off(U1 - 1 - r));
-          b[j] = (B == 0 && FULL == 0 && r == 0) ? lds_rd(win_t + win_off(kFbRing)) : lds_rd(p2 + win_off(U2 + 1 + r));
+        for (int q = 0; q < 4; ++q) {
+          nr[q] = cr[64 * (s + 4 + q)];
+          ni[q] = ci[64 * (s + 4 + q)];
         }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = 8 * g + j;
-        if (r < REM) {
-          re = fma(a[j] + b[j], cc[j].x, re);
-          im = fma(a[j] - b[j], cc[j].y, im);
+      for (int q = 0; q < 4; ++q) step(kr[q], ki[q]);
+    }
+    for (; s < n; ++s) step(cr[64 * s], ci[64 * s]);
+    // D layout: column = lane & 15 (time), row = (lane >> 4) + 4 i  ->  band 16 r + row
+    const v4d accr[4] = {ar0, ar1, ar2, ar3}, acci[4] = {ai0, ai1, ai2, ai3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = 16 * r + kk + 4 * i;
+      if (b < kFbBands) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          atomicAdd(&sh.a.re[b][16 * nt + j], accr[nt][i]);
+          atomicAdd(&sh.a.im[b][16 * nt + j], acci[nt][i]);
         }
       }
-      if (g + 1 < REMG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) cc[j] = cn[j];
-      }
     }
+    g += n;
   }
-  gcoef_t hcv = hc + H;
-  GROUP_FENCE(hcv);
-#undef GROUP_FENCE
-  const double xm = win_t[win_off(U1 - H)];          // centre tap, once
-  const v2d ch = *hcv;
-  re_out = fma(xm, ch.x, re);
-  im_out = fma(xm, ch.y, im);
 }
 
-// the ten bands of wave w: { w, 7-w, 8+w, 15-w, 16+w, 23-w, 24+w, 31-w, 32+w, 39-w } --
-// a longest-first deal of the filter lengths: 2728 tap pairs per wave
+// the ten bands a wave carries through phases 2..: { w, 7-w, 8+w, 15-w, 16+w, 23-w, 24+w, 31-w, 32+w, 39-w }
+__host__ __device__ constexpr int wave_band(int w, int i) { return (i & 1) ? 8 * (i >> 1) + 7 - w : 8 * (i >> 1) + w; }
+
+// upward spreading of wave W's ten source bands (ascending: wave_band(W, 0) < ... < wave_band(W, 9)):
+// target band j receives sum_{sources b < j} A[b] cu_b^(j-b); everything about the band indices
+// is a compile-time constant, the code is a straight line of multiplies, adds and 78 atomics
 template <int W>
-__device__ __forceinline__ void fir_wave(const double* win_t, const double2* coef, double (&re)[10], double (&im)[10]) {
-  // scheduling fences: the ten filters are independent, without them the scheduler overlaps
-  // their load phases and runs out of registers
-  fir_band<W>(win_t, coef, re[0], im[0]);
-  __builtin_amdgcn_sched_barrier(0);
-  fir_band<7 - W>(win_t, coef, re[1], im[1]);
-  __builtin_amdgcn_sched_barrier(0);
-  fir_band<8 + W>(win_t, coef, re[2], im[2]);
-  __builtin_amdgcn_sched_barrier(0);
-  fir_band<15 - W>(win_t, coef, re[3], im[3]);
-  __builtin_amdgcn_sched_barrier(0);
-  fir_band<16 + W>(win_t, coef, re[4], im[4]);
-  __builtin_amdgcn_sched_barrier(0);
-  fir_band<23 - W>(win_t, coef, re[5], im[5]);
-  __builtin_amdgcn_sched_barrier(0);
-  fir_band<24 + W>(win_t, coef, re[6], im[6]);
-  __builtin_amdgcn_sched_barrier(0);
-  fir_band<31 - W>(win_t, coef, re[7], im[7]);
-  __builtin_amdgcn_sched_barrier(0);
-  fir_band<32 + W>(win_t, coef, re[8], im[8]);
-  __builtin_amdgcn_sched_barrier(0);
-  fir_band<39 - W>(win_t, coef, re[9], im[9]);
-  __builtin_amdgcn_sched_barrier(0);
+__device__ __forceinline__ void spread_up(BankLds& sh, const double (&re)[10], const double (&im)[10],
+                                          const double (&cu)[10], int lane) {
+  double tr[10], ti[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    tr[i] = re[i];
+    ti[i] = im[i];
+  }
+#pragma unroll
+  for (int j = 1; j < kFbBands; ++j) {
+    double sr = 0., si = 0.;
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      if (wave_band(W, i) < j) {                     // compile time
+        tr[i] *= cu[i];
+        ti[i] *= cu[i];
+        sr += tr[i];
+        si += ti[i];
+        any = true;
+      }
+    }
+    if (any) {
+      atomicAdd(&sh.a.re[j][lane], sr);
+      atomicAdd(&sh.a.im[j][lane], si);
+    }
+  }
 }
-__device__ __forceinline__ int wave_band(int w, int i) { return (i & 1) ? 8 * (i >> 1) + 7 - w : 8 * (i >> 1) + w; }
 
-__global__ __launch_bounds__(256, 3) void fb_bank_kernel(FbFrontArgs a, unsigned n_signals) {
+__global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned n_signals) {
   __shared__ BankLds sh;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -362,7 +353,6 @@ __global__ __launch_bounds__(256, 3) void fb_bank_kernel(FbFrontArgs a, unsigned
   const unsigned nb_mine = min(a.blocks_per_launch, n_blocks - a.block0);
   const BandTables* __restrict__ bt = a.bands;
   const FbTables* __restrict__ fb = a.fb;
-  const double2* __restrict__ coef = reinterpret_cast<const double2*>(fb->h_ri);
   const size_t row_len = a.hp_row_stride;
   const size_t row_valid = (size_t)kFbRing + (size_t)a.blocks_per_launch * kFbFrame;
   const double* __restrict__ row = a.hp_scratch + (size_t)g * row_len;
@@ -387,7 +377,6 @@ __global__ __launch_bounds__(256, 3) void fb_bank_kernel(FbFrontArgs a, unsigned
     }
     decay = acc;
   }
-  const int t = lane < kTileSub ? lane : kTileSub - 1;
 
   for (unsigned b0 = 0; b0 < nb_mine; b0 += kTileBlocks) {
     const unsigned nvb = min((unsigned)kTileBlocks, nb_mine - b0);   // valid blocks in this tile
@@ -398,32 +387,39 @@ __global__ __launch_bounds__(256, 3) void fb_bank_kernel(FbFrontArgs a, unsigned
       const double* src = row + (size_t)b0 * kFbFrame;               // row index 0 = sample -1456 of the launch
       const int avail = (int)min((size_t)kWin, row_valid - (size_t)b0 * kFbFrame);
       for (int wdx = tid; wdx < kWin; wdx += 256) sh.win[win_off(wdx)] = wdx < avail ? src[wdx] : 0.;
+      double* az = &sh.a.re[0][0];
+      for (int i = tid; i < 2 * kFbBands * kACols; i += 256) az[i] = 0.;
     }
     __syncthreads();
-    // ---- phase 1: the complex FIR filters (fbearmodel.c:399-435) ---------------------------------
+    // ---- phase 1: the complex FIR filters (fbearmodel.c:399-435) as a GEMM on the matrix cores ---
+    fir_mfma(sh, fb->mf_re, fb->mf_im, wv, lane);
+    __syncthreads();                                                 // A is complete
+    // ---- phase 2a: every wave picks up its ten bands at its time point ---------------------------
     double re[10], im[10];
-    {
-      const double* win_t = sh.win + t;
-      switch (wv) {
-        case 0: fir_wave<0>(win_t, coef, re, im); break;
-        case 1: fir_wave<1>(win_t, coef, re, im); break;
-        case 2: fir_wave<2>(win_t, coef, re, im); break;
-        default: fir_wave<3>(win_t, coef, re, im); break;
-      }
-    }
-    __syncthreads();                                                 // everybody is done with the window
-    // ---- phase 2a: A = filter outputs (overlays the window) ----------------------------------------
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       const int b = wave_band(wv, i);
-      sh.a.re[b][lane] = re[i];
-      sh.a.im[b][lane] = im[i];
+      re[i] = sh.a.re[b][lane];
+      im[i] = sh.a.im[b][lane];
     }
-    __syncthreads();
+    if (wv == 0) {
+      // band 0 (= re[0] of wave 0): its tap at delay 1456 reads the NEWEST sample in the reference
+      // (the doubled ring buffer makes fb_buf[offset + 1456] alias fb_buf[offset], fbearmodel.c:413-414)
+      const int tt = lane < kTileSub ? lane : kTileSub - 1;
+      const double delta = sh.win[win_off(kFbRing) + tt] - sh.win[win_off(0) + tt];
+      re[0] = fma(fb->h_re[1], delta, re[0]);
+      im[0] = fma(-fb->h_im[1], delta, im[0]);
+      sh.a.re[0][lane] = re[0];                      // band 0 is nobody's spreading target
+      sh.a.im[0][lane] = im[0];
+    }
+    __syncthreads();                                                 // ... before phase 2b adds into A
     // ---- phase 2b: level-dependent upward spreading (fbearmodel.c:327-349).  The slope
     // filter runs along time = along the lanes (inclusive scan with the carried-in state);
-    // every source band adds its geometric tail into the bands above it with LDS atomics
-    // (one column per lane: no contention inside an instruction) -----------------------------------
+    // every source band adds its geometric tail into the bands above it.  A wave first sums
+    // the tails of ITS ten sources per target band in registers and then issues ONE LDS atomic
+    // per target and part (312 per tile instead of 1560; one column per lane: no contention
+    // inside an instruction) ------------------------------------------------------------------------
+    double cuv[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       const int b = wave_band(wv, i);
@@ -440,13 +436,13 @@ __global__ __launch_bounds__(256, 3) void fb_bank_kernel(FbFrontArgs a, unsigned
       const double cu = v + decay * sh.cu[b];
       const double carry = __shfl(cu, nvs - 1, 64);
       if (lane == 0) sh.cu[b] = carry;                               // only this wave touches cu[b]
-      double d1 = re[i], d2 = im[i];
-      for (int j = b + 1; j < kFbBands; ++j) {
-        d1 *= cu;
-        d2 *= cu;
-        atomicAdd(&sh.a.re[j][lane], d1);
-        atomicAdd(&sh.a.im[j][lane], d2);
-      }
+      cuv[i] = cu;
+    }
+    switch (wv) {
+      case 0: spread_up<0>(sh, re, im, cuv, lane); break;
+      case 1: spread_up<1>(sh, re, im, cuv, lane); break;
+      case 2: spread_up<2>(sh, re, im, cuv, lane); break;
+      default: spread_up<3>(sh, re, im, cuv, lane); break;
     }
     __syncthreads();
     // ---- phase 3: downward spreading (fbearmodel.c:351-354): wave 0 the real, wave 1 the

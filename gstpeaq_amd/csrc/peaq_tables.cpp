@@ -13,6 +13,7 @@
 #include "peaq_tables.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -169,6 +170,30 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
       fb.h_ri[2 * (off + k) + 1] = fb.h_im[off + k];
     }
     off += len / 2 + 1;
+  }
+  // GEMM form of the bank (peaq_device.h): tap n = 1 .. N/2 of band b sits at delay d = D_b + n and
+  // shares its coefficient (conjugated) with the tap at delay 1458 - d.  Band 0's tap at delay 1456
+  // reads the NEWEST sample in the reference (doubled ring buffer, fbearmodel.c:413-414); the kernel
+  // corrects that one product after the GEMM.
+  for (int r = 0; r < kMfTiles; ++r) {
+    const int longest = kLen[16 * r];
+    if (fb.delay[16 * r] + 1 != kMfD0[r] || (kFbCentre - kMfD0[r]) / 4 + 1 != kMfSteps[r] ||
+        fb.delay[16 * r] + longest / 2 != kFbCentre)
+      std::abort();                                      // peaq_device.h constants
+    for (int s = 0; s < kMfSteps[r]; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int b = 16 * r + (lane & 15), d = kMfD0[r] + 4 * s + (lane >> 4);
+        double vr = 0., vi = 0.;
+        if (b < kFbBands) {
+          const int half = kLen[b] / 2, n = d - fb.delay[b];
+          if (n >= 1 && n <= half) {
+            vr = fb.h_re[fb.coef_off[b] + n] * (n == half ? 0.5 : 1.);
+            vi = n == half ? 0. : fb.h_im[fb.coef_off[b] + n];
+          }
+        }
+        fb.mf_re[(size_t)(kMfBase[r] + s) * 64 + lane] = vr;
+        fb.mf_im[(size_t)(kMfBase[r] + s) * 64 + lane] = vi;
+      }
   }
   for (int k = 0; k < 6; ++k) {
     const double c = std::cos(kPi * (k - 5.0) / 12.0);
