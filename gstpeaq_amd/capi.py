@@ -247,7 +247,7 @@ def _stream_ptr(stream):
     if stream is None:
         import torch
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    return C.c_void_p(int(stream))
+    return C.c_void_p(int(getattr(stream, "cuda_stream", stream)))   # torch.cuda.Stream or a raw hipStream_t
 
 
 def batch_run(ctx, advanced, ref, test, n_ref=None, n_test=None, playback_level=92.0, results=None,
