@@ -378,10 +378,16 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
     decay = acc;
   }
 
+  constexpr double kC1 = -2. * kLnDist / 2.302585092994046;         // -0.2 * 10 / ln 10 * ln DIST
+  double c0[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) c0[i] = kLnDist * (24. + 230. / bt->fc[wave_band(wv, i)]);
+
   for (unsigned b0 = 0; b0 < nb_mine; b0 += kTileBlocks) {
     const unsigned nvb = min((unsigned)kTileBlocks, nb_mine - b0);   // valid blocks in this tile
     const int nvs = 6 * nvb;                                         // valid sub-samples
-    __syncthreads();                                                 // previous tile is done with the LDS
+    // (no barrier here: after the last barrier of the previous tile nobody reads the window or A
+    // any more; wave 0 may still be in its phase 5, which only touches e1 and global memory)
     // ---- phase 0: window of the filtered signal, samples [192 b0 - 1456, 192 b0 + 59*32] ------
     {
       const double* src = row + (size_t)b0 * kFbFrame;               // row index 0 = sample -1456 of the launch
@@ -423,9 +429,9 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       const int b = wave_band(wv, i);
-      const double level = 10. * log10(re[i] * re[i] + im[i] * im[i]);
-      const double slope = fmax(4., 24. + 230. / bt->fc[b] - 0.2 * level);
-      const double dist_s = exp(slope * kLnDist);                    // pow(DIST, s)
+      // pow(DIST, s), s = max(4, 24 + 230/fc - 0.2 L), L = 10 log10 |A|^2 (fbearmodel.c:329-333), as
+      // exp(min(4 ln DIST, ln DIST (24 + 230/fc) - 2 ln DIST / ln 10 * ln |A|^2))  (ln DIST < 0)
+      const double dist_s = exp(fmin(4. * kLnDist, c0[i] + kC1 * log(re[i] * re[i] + im[i] * im[i])));
       double v = kSlopeA * dist_s, m = 1. - kSlopeA;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
