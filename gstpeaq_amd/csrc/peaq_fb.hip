@@ -383,16 +383,32 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
 #pragma unroll
   for (int i = 0; i < 10; ++i) c0[i] = kLnDist * (24. + 230. / bt->fc[wave_band(wv, i)]);
 
+  constexpr int kKeep = kWin - kTileSub * 32;                       // 1425 samples shared by consecutive tiles
+  constexpr int kPre = (kWin - kKeep + 255) / 256;                  // new samples per thread (8)
+  double pre[kPre];
+#pragma unroll
+  for (int q = 0; q < kPre; ++q) pre[q] = 0.;
+
   for (unsigned b0 = 0; b0 < nb_mine; b0 += kTileBlocks) {
     const unsigned nvb = min((unsigned)kTileBlocks, nb_mine - b0);   // valid blocks in this tile
     const int nvs = 6 * nvb;                                         // valid sub-samples
     // (no barrier here: after the last barrier of the previous tile nobody reads the window or A
     // any more; wave 0 may still be in its phase 5, which only touches e1 and global memory)
-    // ---- phase 0: window of the filtered signal, samples [192 b0 - 1456, 192 b0 + 59*32] ------
+    // ---- phase 0: window of the filtered signal, samples [192 b0 - 1456, 192 b0 + 59*32].  Only the
+    // first tile reads all of it; later tiles keep the 1425 samples they share with their
+    // predecessor (moved inside LDS) and take the 1920 new ones from registers, where they were
+    // requested a whole tile ago (see below phase 2a) -------------------------------------------------
+    if (b0 == 0) {
+      const int avail = (int)min((size_t)kWin, row_valid);
+      for (int wdx = tid; wdx < kWin; wdx += 256) sh.win[win_off(wdx)] = wdx < avail ? row[wdx] : 0.;
+    } else {
+#pragma unroll
+      for (int q = 0; q < kPre; ++q) {
+        const int wdx = kKeep + tid + 256 * q;
+        if (wdx < kWin) sh.win[win_off(wdx)] = pre[q];
+      }
+    }
     {
-      const double* src = row + (size_t)b0 * kFbFrame;               // row index 0 = sample -1456 of the launch
-      const int avail = (int)min((size_t)kWin, row_valid - (size_t)b0 * kFbFrame);
-      for (int wdx = tid; wdx < kWin; wdx += 256) sh.win[win_off(wdx)] = wdx < avail ? src[wdx] : 0.;
       double* az = &sh.a.re[0][0];
       for (int i = tid; i < 2 * kFbBands * kACols; i += 256) az[i] = 0.;
     }
@@ -419,6 +435,23 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       sh.a.im[0][lane] = im[0];
     }
     __syncthreads();                                                 // ... before phase 2b adds into A
+    // ---- the next tile's window: nobody reads this tile's any more.  Its last 45 columns become
+    // the next tile's first 45 (a tile advances by 60 columns = 1920 samples); the new samples are
+    // requested now and land in registers while phases 2b..5 run ---------------------------------------
+    if (b0 + kTileBlocks < nb_mine) {
+      for (int e = tid; e < 32 * (kWinCols - kTileSub); e += 256) {
+        const int r = e / (kWinCols - kTileSub), c = e - r * (kWinCols - kTileSub);
+        sh.win[r * kWinRow + c] = sh.win[r * kWinRow + kTileSub + c];
+      }
+      const size_t first = (size_t)(b0 + kTileBlocks) * kFbFrame;    // row index of the next window's u = 0
+      const double* src = row + first;
+      const int avail = (int)min((size_t)kWin, row_valid - first);
+#pragma unroll
+      for (int q = 0; q < kPre; ++q) {
+        const int wdx = kKeep + tid + 256 * q;
+        pre[q] = wdx < avail ? src[wdx] : 0.;
+      }
+    }
     // ---- phase 2b: level-dependent upward spreading (fbearmodel.c:327-349).  The slope
     // filter runs along time = along the lanes (inclusive scan with the carried-in state);
     // every source band adds its geometric tail into the bands above it.  A wave first sums
