@@ -34,13 +34,13 @@ FLOP_PER_FRAME_PAIR = 0.45e6          # SURVEY.md 8(d), reported alongside
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 
-def cpu_baseline(n_samples, channels, seed0, budget_s=15.0):
+def cpu_baseline(n_samples, channels, seed0, budget_s=12.0):
     """frame-pairs/s of the reference C path on ONE host core, bounded sample."""
     cores = 1
     ref_bin = ROOT / "oracle" / "_ref" / "ref_harness"
     env = dict(os.environ)
-    # one 10 s stereo pair is ~0.2 s on the reference, ~0.3 s on the oracle
-    pairs = max(2, int(budget_s / 0.35))
+    # one 10 s stereo pair is ~0.055 s on the reference element, ~0.3 s on the oracle
+    pairs = max(2, int(budget_s / 0.055))
     try:
         if ref_bin.exists():
             out = subprocess.run([str(ref_bin), "time", "0", str(channels), str(seed0), str(pairs), str(n_samples)],
@@ -53,6 +53,7 @@ def cpu_baseline(n_samples, channels, seed0, budget_s=15.0):
                                    f"{d['seconds']:.1f} s; host has {os.cpu_count()} cores")
     except Exception:
         pass
+    pairs = max(2, int(budget_s / 0.3))
     cli = ROOT / "oracle" / "oracle_cli"
     if not cli.exists():
         subprocess.run(["make", "-C", str(ROOT / "oracle"), "oracle_cli"], capture_output=True)
