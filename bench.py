@@ -34,17 +34,17 @@ FLOP_PER_FRAME_PAIR = 0.45e6          # SURVEY.md 8(d), reported alongside
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 
-def cpu_baseline(n_samples, channels, seed0, budget_s=12.0):
+def cpu_baseline(n_samples, channels, seed0, advanced=False, budget_s=12.0):
     """frame-pairs/s of the reference C path on ONE host core, bounded sample."""
     cores = 1
     ref_bin = ROOT / "oracle" / "_ref" / "ref_harness"
     env = dict(os.environ)
     # one 10 s stereo pair is ~0.055 s on the reference element, ~0.3 s on the oracle
-    pairs = max(2, int(budget_s / 0.055))
+    pairs = max(2, int(budget_s / (0.75 if advanced else 0.055)))
     try:
         if ref_bin.exists():
-            out = subprocess.run([str(ref_bin), "time", "0", str(channels), str(seed0), str(pairs), str(n_samples)],
-                                 capture_output=True, text=True, timeout=120, env=env)
+            out = subprocess.run([str(ref_bin), "time", str(int(advanced)), str(channels), str(seed0), str(pairs), str(n_samples)],
+                                 capture_output=True, text=True, timeout=240, env=env)
             if out.returncode == 0:
                 d = json.loads(out.stdout.strip().splitlines()[-1])
                 return dict(value=d["frame_pairs_per_s"], unit="frame-pairs/s", cores=cores, kind="reference",
@@ -53,11 +53,11 @@ def cpu_baseline(n_samples, channels, seed0, budget_s=12.0):
                                    f"{d['seconds']:.1f} s; host has {os.cpu_count()} cores")
     except Exception:
         pass
-    pairs = max(2, int(budget_s / 0.3))
+    pairs = max(2, int(budget_s / (1.5 if advanced else 0.3)))
     cli = ROOT / "oracle" / "oracle_cli"
     if not cli.exists():
         subprocess.run(["make", "-C", str(ROOT / "oracle"), "oracle_cli"], capture_output=True)
-    out = subprocess.run([str(cli), "time", "0", str(channels), str(seed0), str(pairs), str(n_samples)],
+    out = subprocess.run([str(cli), "time", str(int(advanced)), str(channels), str(seed0), str(pairs), str(n_samples)],
                          capture_output=True, text=True, timeout=180)
     d = json.loads(out.stdout.strip().splitlines()[-1])
     return dict(value=d["frame_pairs_per_s"], unit="frame-pairs/s", cores=cores, kind="port",
@@ -175,7 +175,7 @@ def main():
             "odg_nan": int(torch.isnan(odg).sum().item()),
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(n_samples, args.channels, seed0)
+            line["cpu_baseline"] = cpu_baseline(n_samples, args.channels, seed0, args.advanced)
         print(json.dumps(line))
     if dist:
         dist.barrier()
