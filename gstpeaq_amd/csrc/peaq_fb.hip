@@ -194,6 +194,7 @@ struct BankLds {
     double im[kFbBands][kACols];
   } a;
   double e1[kFbBands][kTileBlocks];
+  double ex[kFbBands][kTileBlocks];                 // excitation per (band, block) on its way to the records
   double hist[kFbBands][10];       // the 10 newest E0 values of the previous tile, oldest first
   double cu[kFbBands];
 };
@@ -409,8 +410,8 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       }
     }
     {
-      double* az = &sh.a.re[0][0];
-      for (int i = tid; i < 2 * kFbBands * kACols; i += 256) az[i] = 0.;
+      double2* az = reinterpret_cast<double2*>(&sh.a.re[0][0]);
+      for (int i = tid; i < kFbBands * kACols; i += 256) az[i] = make_double2(0., 0.);
     }
     __syncthreads();
     // ---- phase 1: the complex FIR filters (fbearmodel.c:399-435) as a GEMM on the matrix cores ---
@@ -537,16 +538,23 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       const int item = tid + 256 * rep;
       if (item < kFbBands * 10) sh.hist[item / 10][item % 10] = hnew[rep];
     }
-    // ---- phase 5: internal noise + forward masking (fbearmodel.c:385-394), thread = band ------------
+    // ---- phase 5: internal noise + forward masking (fbearmodel.c:385-394).  The recurrence along
+    // the blocks is walked by one thread per band into LDS; then all threads write the records --------
     if (tid < kFbBands) {
       const double noise = bt->internal_noise[tid], ac = bt->ear_tc[tid];
       for (unsigned bl = 0; bl < nvb; ++bl) {
         const double unsm = sh.e1[tid][bl] + noise;
         exc = ac * exc + (1. - ac) * unsm;
-        double* rec = a.records + ((size_t)(pair * a.blocks_per_launch + b0 + bl) * a.channels + chan) * kFbRecDoubles;
-        rec[(sig ? kFbRecUnsmTest : kFbRecUnsmRef) + tid] = unsm;
-        rec[(sig ? kFbRecExcTest : kFbRecExcRef) + tid] = exc;
+        sh.e1[tid][bl] = unsm;
+        sh.ex[tid][bl] = exc;
       }
+    }
+    __syncthreads();
+    for (int item = tid; item < kFbBands * (int)nvb; item += 256) {
+      const int bl = item / kFbBands, b = item - bl * kFbBands;      // 40 consecutive doubles per block
+      double* rec = a.records + ((size_t)(pair * a.blocks_per_launch + b0 + bl) * a.channels + chan) * kFbRecDoubles;
+      rec[(sig ? kFbRecUnsmTest : kFbRecUnsmRef) + b] = sh.e1[b][bl];
+      rec[(sig ? kFbRecExcTest : kFbRecExcRef) + b] = sh.ex[b][bl];
     }
   }
   __syncthreads();
