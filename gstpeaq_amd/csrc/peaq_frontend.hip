@@ -530,34 +530,9 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     } else if (lane < (NB + 1) / 2 + kBandStride - NB) {
       rec[kRecNoise + NB + lane - (NB + 1) / 2] = 0.;  // padding slots of the band vector
     }
-    // ---- totalsnr energies over the hop (gstpeaq.c:913-918; float products) --------
-    double se = 0., ne = 0.;
-    int lane_q = lane;                               // opaque copy, see above
-    asm volatile("" : "+v"(lane_q));
-    auto hop_energy = [&](auto whole) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int n = lane_q + 64 * r;
-        float r0, r1, t0, t1;
-        src_ref.template load2<decltype(whole)::value>(n, r0, r1);
-        src_test.template load2<decltype(whole)::value>(n, t0, t1);
-        se += (double)(r0 * r0);
-        se += (double)(r1 * r1);
-        ne += (double)((r0 - t0) * (r0 - t0));
-        ne += (double)((r1 - t1) * (r1 - t1));
-      }
-    };
-    if (src_ref.whole && src_test.whole)
-      hop_energy(std::true_type{});
-    else
-      hop_energy(std::false_type{});
-    se = wave_sum(se);
-    ne = wave_sum(ne);
     if (lane == 0) {
       rec[kRecBwRef] = (double)bw_ref;
       rec[kRecBwTest] = (double)bw_test;
-      rec[kRecSigE] = se;
-      rec[kRecNoiseE] = ne;
     }
   } else {
     // ---- error harmonic structure, part 3 (movs.c:1393-1441): lane owns lags lane + 64 m ----
@@ -644,6 +619,34 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     if (lane == 0 && s2 > s1_last && s2 > best) best = s2;
     best = wave_max(best);
     if (lane == 0) rec[kRecEhs] = best;
+    // ---- totalsnr energies over the hop (gstpeaq.c:913-918; float products).  Done by the
+    // reference wave: its tail (EHS part 3) is shorter than the test wave's (noise spectrum) --------
+    double se = 0., ne = 0.;
+    int lane_q = lane;                               // opaque copy, see above
+    asm volatile("" : "+v"(lane_q));
+    auto hop_energy = [&](auto whole) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int n = lane_q + 64 * r;
+        float r0, r1, t0, t1;
+        src_ref.template load2<decltype(whole)::value>(n, r0, r1);
+        src_test.template load2<decltype(whole)::value>(n, t0, t1);
+        se += (double)(r0 * r0);
+        se += (double)(r1 * r1);
+        ne += (double)((r0 - t0) * (r0 - t0));
+        ne += (double)((r1 - t1) * (r1 - t1));
+      }
+    };
+    if (src_ref.whole && src_test.whole)
+      hop_energy(std::true_type{});
+    else
+      hop_energy(std::false_type{});
+    se = wave_sum(se);
+    ne = wave_sum(ne);
+    if (lane == 0) {
+      rec[kRecSigE] = se;
+      rec[kRecNoiseE] = ne;
+    }
   }
 }
 
