@@ -90,7 +90,7 @@ def load_library():
                                       C.c_int, dp]
     L.peaq_debug_filterbank.argtypes = [vp, C.c_int, C.c_double, vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, dp]
     ip = C.POINTER(C.c_int)
-    L.peaq_broker_create.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.POINTER(vp)]
+    L.peaq_broker_create.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(vp)]
     L.peaq_broker_destroy.argtypes = [vp]
     L.peaq_broker_destroy.restype = None
     L.peaq_broker_open.argtypes = [vp, ip]
@@ -187,12 +187,12 @@ class Session:
 class Broker:
     """Many live sessions (one per hosted `peaq` element), one batched launch per tick."""
 
-    def __init__(self, ctx, channels, max_sessions, playback_level=92.0):
-        self.ctx, self.channels = ctx, channels
+    def __init__(self, ctx, channels, max_sessions, playback_level=92.0, advanced=False):
+        self.ctx, self.channels, self.advanced = ctx, channels, bool(advanced)
         self.L = ctx.L
         self.h = C.c_void_p()
-        _check(self.L.peaq_broker_create(ctx.h, int(channels), float(playback_level), int(max_sessions),
-                                         C.byref(self.h)))
+        _check(self.L.peaq_broker_create(ctx.h, int(bool(advanced)), int(channels), float(playback_level),
+                                         int(max_sessions), C.byref(self.h)))
 
     def open(self):
         sid = C.c_int(-1)
@@ -218,7 +218,7 @@ class Broker:
     def results(self, sid):
         out = np.zeros(RESULT_DOUBLES)
         _check(self.L.peaq_broker_results(self.h, int(sid), out.ctypes.data_as(C.POINTER(C.c_double))))
-        return _result_dict(out, False)
+        return _result_dict(out, self.advanced)
 
     def start(self, period_us=2000):
         _check(self.L.peaq_broker_start(self.h, int(period_us)))

@@ -659,12 +659,21 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
   const unsigned pair = blockIdx.x;
   const GlobalTabs bt{a.bands};
   const BandLane<NB, SLOTS> bl{lane};
-  PairState* __restrict__ ps = a.state + pair;
+  unsigned b_begin, b_end, slot = pair;
+  if (a.windows) {                                   // broker launch: this session's own window and state
+    const FbPairWindow w = a.windows[pair];
+    b_begin = w.block0;
+    b_end = w.block0 + w.n_blocks;
+    slot = w.slot;
+  } else {
+    const unsigned n_blocks = a.n_blocks ? a.n_blocks[pair] : a.n_blocks_uniform;
+    b_begin = a.block0;
+    b_end = a.block0 + a.blocks_per_launch;
+    if (b_end > n_blocks) b_end = n_blocks;
+  }
+  if (b_begin >= b_end) return;
+  PairState* __restrict__ ps = a.state + slot;
   ChannelState* __restrict__ cs = &ps->ch[chan];
-  const unsigned n_blocks = a.n_blocks ? a.n_blocks[pair] : a.n_blocks_uniform;
-  unsigned b_end = a.block0 + a.blocks_per_launch;
-  if (b_end > n_blocks) b_end = n_blocks;
-  if (a.block0 >= b_end) return;
 
   const int bb = lane < kBandStride ? lane : 0;
   double la[6][SLOTS], mdr[3][SLOTS], mdt[3][SLOTS];
@@ -686,9 +695,9 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
   const bool owns = lane == MA_RMSMOD || lane == MA_NLASYM || lane == MA_LINDIST;
   unsigned loud_reached = ps->loudness_reached;
 
-  for (unsigned blk = a.block0; blk < b_end; ++blk) {
+  for (unsigned blk = b_begin; blk < b_end; ++blk) {
     const double* __restrict__ rec0 =
-        a.records + ((size_t)(pair * a.blocks_per_launch + (blk - a.block0)) * channels) * kFbRecDoubles;
+        a.records + ((size_t)(pair * a.blocks_per_launch + (blk - b_begin)) * channels) * kFbRecDoubles;
     const double* __restrict__ rec = rec0 + (size_t)chan * kFbRecDoubles;
     // boundary detector on the 192-sample block, any reference channel (gstpeaq.c:971-979)
     bool above = rec0[kFbRecFlags] != 0.;

@@ -939,32 +939,59 @@ extern "C" int peaq_session_reset(peaq_session* s) {
 // A process that hosts many `peaq` elements (BASELINE.json configs[5]: 1024
 // concurrent live pipelines) would otherwise issue one 1-workgroup launch pair
 // per element and buffer.  The broker keeps the FIFOs of all its sessions on
-// the host and, on every tick, gathers whatever frames became ready in ANY
-// session into ONE front-end and ONE back-end launch: workgroup (pair p, frame
-// fl) of that grid is frame pair_frame0[p] + fl of session pair_slot[p].  The
-// recurrent state of a session stays in its PairState slot in HBM between
-// ticks, so the result of a session is the same whether its frames were run
-// alone, in a batch, or interleaved with other sessions' frames.
-// Basic model only (the filter-bank path of the advanced model has no per-pair
-// block windows yet); the framing per session is that of do_processing /
-// do_flush (gstpeaq.c:596-611, 716-745).
+// the host and, on every tick, gathers whatever frames (and, in the advanced
+// version, filter-bank blocks) became ready in ANY session into ONE launch per
+// kernel: workgroup (pair p, frame fl) of the front-end grid is frame
+// pair_frame0[p] + fl of session pair_slot[p]; the filter-bank kernels get a
+// FbPairWindow per session.  The recurrent state of a session stays in its slot
+// in HBM between ticks, so the result of a session is the same whether its
+// frames were run alone, in a batch, or interleaved with other sessions'.
+// The framing per session is that of do_processing / do_flush
+// (gstpeaq.c:596-611, 716-745, 769-771).
 namespace {
-constexpr unsigned kBrokerMaxFrames = 8;     // frames one session contributes to one tick
+constexpr unsigned kBrokerMaxFrames = 8;     // FFT frames one session contributes to one tick
+constexpr unsigned kBrokerMaxBlocks = 48;    // filter-bank blocks one session contributes to one tick
 constexpr size_t kBrokerStageSamples = (size_t)(kBrokerMaxFrames - 1) * kHop + kFrame;
+constexpr size_t kBrokerFbStageSamples = (size_t)kBrokerMaxBlocks * kFbFrame;
+constexpr size_t kBrokerRowStride = (size_t)kFbRing + kBrokerFbStageSamples;
 
 struct BrokerSlot {
   std::mutex mu;
   bool open = false;
-  bool flush_requested = false;
+  bool flush_requested = false, fft_flushed = false, fb_flushed = false;
   PadFifo pad[2];
   uint64_t fft_pos[2] = {0, 0};
-  uint32_t frames_done = 0;
+  uint64_t fb_pos[2] = {0, 0};
+  uint32_t frames_done = 0, blocks_done = 0, fb_prev_blocks = 0;
+};
+
+// staging of one kind of unit (FFT frames or filter-bank blocks): pinned host + device buffers
+struct BrokerStage {
+  float* h[2] = {nullptr, nullptr};         // [launch pair][stage samples][channels]
+  DevBuf d[2];
+  size_t samples = 0;
+  int alloc(size_t n_sessions, size_t stage_samples, int channels) {
+    samples = stage_samples;
+    const size_t bytes = n_sessions * stage_samples * channels * sizeof(float);
+    for (int p = 0; p < 2; ++p) {
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h[p]), bytes, hipHostMallocDefault));
+      HIP_TRY(d[p].reserve(bytes));
+    }
+    return PEAQ_OK;
+  }
+  void release() {
+    for (int p = 0; p < 2; ++p) {
+      if (h[p]) (void)hipHostFree(h[p]);
+      h[p] = nullptr;
+      d[p].release();
+    }
+  }
 };
 }  // namespace
 
 struct peaq_broker {
   peaq_ctx* ctx = nullptr;
-  int channels = 1;
+  int advanced = 0, channels = 1;
   double level_db = 92.;
   int max_sessions = 0;
   std::vector<BrokerSlot*> slots;
@@ -972,9 +999,10 @@ struct peaq_broker {
   hipStream_t stream = nullptr;
   hipEvent_t staged = nullptr;
   bool staged_pending = false;
-  float* h_stage[2] = {nullptr, nullptr};   // pinned, [launch pair][kBrokerStageSamples][channels]
-  uint32_t* h_meta = nullptr;               // pinned, 5 rows of max_sessions: n_ref, n_test, frame0, nframes, slot
-  DevBuf d_sig[2], d_meta, records, state, result;
+  BrokerStage fft, fbs;
+  uint32_t* h_meta = nullptr;       // pinned: 5 rows of max_sessions (n_ref, n_test, frame0, nframes, slot) + 2 rows (fb n_ref, n_test)
+  FbPairWindow* h_win = nullptr;    // pinned: one per launch pair of the filter-bank launch
+  DevBuf d_meta, d_win, records, fb_records, state, fbstate, hp_rows, result;
   std::thread worker;
   std::atomic<bool> running{false};
   unsigned period_us = 0;
@@ -982,6 +1010,18 @@ struct peaq_broker {
   uint64_t n_ticks = 0, n_launches = 0, n_frames = 0;
   uint32_t max_active = 0;
 };
+
+// copies nv[p] samples per pad from the slot's FIFOs at pos[] into staging entry `idx`
+static void broker_stage_copy(const peaq_broker* b, const BrokerSlot& sl, const BrokerStage& st, unsigned idx,
+                              const uint64_t pos[2], const uint64_t nv[2]) {
+  const size_t stride = st.samples * b->channels;
+  for (int p = 0; p < 2; ++p) {
+    const PadFifo& f = sl.pad[p];
+    if (nv[p])
+      std::memcpy(st.h[p] + idx * stride, f.buf.data() + (size_t)(pos[p] - f.base) * b->channels,
+                  (size_t)nv[p] * b->channels * sizeof(float));
+  }
+}
 
 static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
   peaq_ctx* c = b->ctx;
@@ -997,93 +1037,169 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
   uint32_t* m_f0 = b->h_meta + 2 * S;
   uint32_t* m_nf = b->h_meta + 3 * S;
   uint32_t* m_slot = b->h_meta + 4 * S;
-  const size_t stride = kBrokerStageSamples * b->channels;   // floats per launch pair
-  unsigned active = 0, max_nf = 0;
+  uint32_t* m_fb_nref = b->h_meta + 5 * S;
+  uint32_t* m_fb_ntest = b->h_meta + 6 * S;
+  unsigned active = 0, max_nf = 0, fb_active = 0, max_nb = 0;
   uint64_t frames = 0;
   for (int sid = 0; sid < b->max_sessions; ++sid) {
     BrokerSlot& sl = *b->slots[sid];
     std::lock_guard<std::mutex> lock(sl.mu);
     if (!sl.open) continue;
-    const uint64_t left[2] = {sl.pad[0].total - sl.fft_pos[0], sl.pad[1].total - sl.fft_pos[1]};
-    const uint64_t av = std::min(left[0], left[1]);
-    unsigned nf = 0;
-    uint64_t nv[2] = {0, 0}, adv[2] = {0, 0};
-    if (av >= (uint64_t)kFrame) {                                   // do_processing
-      nf = static_cast<unsigned>(std::min<uint64_t>((av - kFrame) / kHop + 1, kBrokerMaxFrames));
-      nv[0] = nv[1] = (uint64_t)(nf - 1) * kHop + kFrame;
-      adv[0] = adv[1] = (uint64_t)nf * kHop;
-    } else if (sl.flush_requested) {                                // do_flush
-      sl.flush_requested = false;
-      if (left[0] || left[1]) {
-        nf = 1;
-        nv[0] = adv[0] = std::min<uint64_t>(left[0], kFrame);
-        nv[1] = adv[1] = std::min<uint64_t>(left[1], kFrame);
+    // ---- FFT frames: do_processing, else the one zero-padded frame of do_flush -------------------
+    {
+      const uint64_t left[2] = {sl.pad[0].total - sl.fft_pos[0], sl.pad[1].total - sl.fft_pos[1]};
+      const uint64_t av = std::min(left[0], left[1]);
+      unsigned nf = 0;
+      uint64_t nv[2] = {0, 0}, adv[2] = {0, 0};
+      if (av >= (uint64_t)kFrame) {
+        nf = static_cast<unsigned>(std::min<uint64_t>((av - kFrame) / kHop + 1, kBrokerMaxFrames));
+        nv[0] = nv[1] = (uint64_t)(nf - 1) * kHop + kFrame;
+        adv[0] = adv[1] = (uint64_t)nf * kHop;
+      } else if (sl.flush_requested && !sl.fft_flushed) {
+        sl.fft_flushed = true;
+        if (left[0] || left[1]) {
+          nf = 1;
+          nv[0] = adv[0] = std::min<uint64_t>(left[0], kFrame);
+          nv[1] = adv[1] = std::min<uint64_t>(left[1], kFrame);
+        }
+      }
+      if (nf) {
+        broker_stage_copy(b, sl, b->fft, active, sl.fft_pos, nv);
+        m_nref[active] = static_cast<uint32_t>(nv[0]);
+        m_ntest[active] = static_cast<uint32_t>(nv[1]);
+        m_f0[active] = sl.frames_done;
+        m_nf[active] = nf;
+        m_slot[active] = static_cast<uint32_t>(sid);
+        sl.fft_pos[0] += adv[0];
+        sl.fft_pos[1] += adv[1];
+        sl.frames_done += nf;
+        frames += nf;
+        max_nf = std::max(max_nf, nf);
+        ++active;
       }
     }
-    if (!nf) continue;
+    // ---- filter-bank blocks (advanced): whole blocks, else the zero-padded block of the flush ----
+    if (b->advanced) {
+      const uint64_t left[2] = {sl.pad[0].total - sl.fb_pos[0], sl.pad[1].total - sl.fb_pos[1]};
+      const uint64_t av = std::min(left[0], left[1]);
+      unsigned nb = 0;
+      uint64_t nv[2] = {0, 0};
+      if (av >= (uint64_t)kFbFrame) {
+        nb = static_cast<unsigned>(std::min<uint64_t>(av / kFbFrame, kBrokerMaxBlocks));
+        nv[0] = nv[1] = (uint64_t)nb * kFbFrame;
+      } else if (sl.flush_requested && !sl.fb_flushed) {
+        sl.fb_flushed = true;
+        if (left[0] || left[1]) {
+          nb = 1;
+          nv[0] = std::min<uint64_t>(left[0], kFbFrame);
+          nv[1] = std::min<uint64_t>(left[1], kFbFrame);
+        }
+      }
+      if (nb) {
+        broker_stage_copy(b, sl, b->fbs, fb_active, sl.fb_pos, nv);
+        m_fb_nref[fb_active] = static_cast<uint32_t>(nv[0]);
+        m_fb_ntest[fb_active] = static_cast<uint32_t>(nv[1]);
+        b->h_win[fb_active] = FbPairWindow{sl.blocks_done, nb, sl.fb_prev_blocks, static_cast<uint32_t>(sid)};
+        sl.fb_pos[0] += nv[0];
+        sl.fb_pos[1] += nv[1];
+        sl.blocks_done += nb;
+        sl.fb_prev_blocks = nb;
+        max_nb = std::max(max_nb, nb);
+        ++fb_active;
+      }
+    }
+    if (sl.flush_requested && sl.fft_flushed && (!b->advanced || sl.fb_flushed))
+      sl.flush_requested = sl.fft_flushed = sl.fb_flushed = false;
+    // drop what both consumers are done with
     for (int p = 0; p < 2; ++p) {
       PadFifo& f = sl.pad[p];
-      if (nv[p])
-        std::memcpy(b->h_stage[p] + active * stride, f.buf.data() + (size_t)(sl.fft_pos[p] - f.base) * b->channels,
-                    (size_t)nv[p] * b->channels * sizeof(float));
-      sl.fft_pos[p] += adv[p];
-      const size_t drop = (size_t)(sl.fft_pos[p] - f.base) * b->channels;
-      f.buf.erase(f.buf.begin(), f.buf.begin() + std::min(drop, f.buf.size()));
-      f.base = sl.fft_pos[p];
+      const uint64_t keep_from = b->advanced ? std::min(sl.fft_pos[p], sl.fb_pos[p]) : sl.fft_pos[p];
+      if (keep_from > f.base) {
+        const size_t drop = (size_t)(keep_from - f.base) * b->channels;
+        f.buf.erase(f.buf.begin(), f.buf.begin() + std::min(drop, f.buf.size()));
+        f.base = keep_from;
+      }
     }
-    m_nref[active] = static_cast<uint32_t>(nv[0]);
-    m_ntest[active] = static_cast<uint32_t>(nv[1]);
-    m_f0[active] = sl.frames_done;
-    m_nf[active] = nf;
-    m_slot[active] = static_cast<uint32_t>(sid);
-    sl.frames_done += nf;
-    frames += nf;
-    max_nf = std::max(max_nf, nf);
-    ++active;
   }
   ++b->n_ticks;
-  if (!active) return PEAQ_OK;
-  for (int p = 0; p < 2; ++p)
-    HIP_TRY(hipMemcpyAsync(b->d_sig[p].p, b->h_stage[p], active * stride * sizeof(float), hipMemcpyHostToDevice,
-                           b->stream));
-  HIP_TRY(hipMemcpyAsync(b->d_meta.p, b->h_meta, 5 * S * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+  if (!active && !fb_active) return PEAQ_OK;
+  HIP_TRY(hipMemcpyAsync(b->d_meta.p, b->h_meta, 7 * S * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
   const uint32_t* d_meta = b->d_meta.as<uint32_t>();
-  FrontendArgs fa{};
-  fa.ref = b->d_sig[0].as<float>();
-  fa.test = b->d_sig[1].as<float>();
-  fa.pair_stride = kBrokerStageSamples;
-  fa.n_ref = d_meta;
-  fa.n_test = d_meta + S;
-  fa.pair_frame0 = d_meta + 2 * S;
-  fa.pair_nframes = d_meta + 3 * S;
-  fa.channels = b->channels;
-  fa.frames_per_launch = max_nf;
-  fa.level_factor = fft_level_factor(b->level_db);
-  fa.common = c->d_common;
-  fa.bands = c->d_bands109;
-  fa.records = b->records.as<double>();
-  HIP_TRY(launch_frontend(109, fa, active, b->stream));
-  BackendArgs ba{};
-  ba.records = fa.records;
-  ba.frames_per_launch = max_nf;
-  ba.channels = b->channels;
-  ba.advanced = 0;
-  ba.bands = fa.bands;
-  ba.state = b->state.as<PairState>();
-  ba.pair_frame0 = fa.pair_frame0;
-  ba.pair_nframes = fa.pair_nframes;
-  ba.pair_slot = d_meta + 4 * S;
-  HIP_TRY(launch_backend(ba, active, b->stream));
+  if (active) {
+    const size_t stride = b->fft.samples * b->channels;
+    for (int p = 0; p < 2; ++p)
+      HIP_TRY(hipMemcpyAsync(b->fft.d[p].p, b->fft.h[p], active * stride * sizeof(float), hipMemcpyHostToDevice,
+                             b->stream));
+    FrontendArgs fa{};
+    fa.ref = b->fft.d[0].as<float>();
+    fa.test = b->fft.d[1].as<float>();
+    fa.pair_stride = b->fft.samples;
+    fa.n_ref = d_meta;
+    fa.n_test = d_meta + S;
+    fa.pair_frame0 = d_meta + 2 * S;
+    fa.pair_nframes = d_meta + 3 * S;
+    fa.channels = b->channels;
+    fa.frames_per_launch = max_nf;
+    fa.level_factor = fft_level_factor(b->level_db);
+    fa.common = c->d_common;
+    fa.bands = b->advanced ? c->d_bands55 : c->d_bands109;
+    fa.records = b->records.as<double>();
+    HIP_TRY(launch_frontend(b->advanced ? 55 : 109, fa, active, b->stream));
+    BackendArgs ba{};
+    ba.records = fa.records;
+    ba.frames_per_launch = max_nf;
+    ba.channels = b->channels;
+    ba.advanced = b->advanced;
+    ba.bands = fa.bands;
+    ba.state = b->state.as<PairState>();
+    ba.pair_frame0 = fa.pair_frame0;
+    ba.pair_nframes = fa.pair_nframes;
+    ba.pair_slot = d_meta + 4 * S;
+    HIP_TRY(launch_backend(ba, active, b->stream));
+  }
+  if (fb_active) {
+    const size_t stride = b->fbs.samples * b->channels;
+    for (int p = 0; p < 2; ++p)
+      HIP_TRY(hipMemcpyAsync(b->fbs.d[p].p, b->fbs.h[p], fb_active * stride * sizeof(float), hipMemcpyHostToDevice,
+                             b->stream));
+    HIP_TRY(hipMemcpyAsync(b->d_win.p, b->h_win, fb_active * sizeof(FbPairWindow), hipMemcpyHostToDevice, b->stream));
+    FbFrontArgs ff{};
+    ff.ref = b->fbs.d[0].as<float>();
+    ff.test = b->fbs.d[1].as<float>();
+    ff.pair_stride = b->fbs.samples;
+    ff.n_ref = d_meta + 5 * S;
+    ff.n_test = d_meta + 6 * S;
+    ff.channels = b->channels;
+    ff.blocks_per_launch = max_nb;
+    ff.level_factor = fb_level_factor(b->level_db);
+    ff.bands = c->d_bands40;
+    ff.fb = c->d_fb;
+    ff.fbstate = b->fbstate.as<FbSignalState>();
+    ff.hp_scratch = b->hp_rows.as<double>();
+    ff.hp_row_stride = kBrokerRowStride;
+    ff.records = b->fb_records.as<double>();
+    ff.windows = b->d_win.as<FbPairWindow>();
+    HIP_TRY(launch_fb_frontend(ff, fb_active, b->stream));
+    FbBackendArgs fbk{};
+    fbk.records = ff.records;
+    fbk.blocks_per_launch = max_nb;
+    fbk.channels = b->channels;
+    fbk.bands = c->d_bands40;
+    fbk.state = b->state.as<PairState>();
+    fbk.windows = ff.windows;
+    HIP_TRY(launch_fb_backend(fbk, fb_active, b->stream));
+  }
   HIP_TRY(hipEventRecord(b->staged, b->stream));
   b->staged_pending = true;
   ++b->n_launches;
   b->n_frames += frames;
-  b->max_active = std::max(b->max_active, active);
-  if (n_active_out) *n_active_out = active;
+  b->max_active = std::max(b->max_active, std::max(active, fb_active));
+  if (n_active_out) *n_active_out = std::max(active, fb_active);
   return PEAQ_OK;
 }
 
-extern "C" int peaq_broker_create(peaq_ctx* c, int channels, double level_db, int max_sessions, peaq_broker** out) {
+extern "C" int peaq_broker_create(peaq_ctx* c, int advanced, int channels, double level_db, int max_sessions,
+                                  peaq_broker** out) {
   if (!c || !out) return fail(PEAQ_ERR_ARG, "peaq_broker_create: NULL argument");
   *out = nullptr;
   if (channels != 1 && channels != 2) return fail(PEAQ_ERR_ARG, "peaq_broker_create: channels must be 1 or 2");
@@ -1094,26 +1210,35 @@ extern "C" int peaq_broker_create(peaq_ctx* c, int channels, double level_db, in
   peaq_broker* b = new (std::nothrow) peaq_broker;
   if (!b) return fail(PEAQ_ERR_NOMEM, "out of host memory");
   b->ctx = c;
+  b->advanced = advanced ? 1 : 0;
   b->channels = channels;
   b->level_db = level_db;
   b->max_sessions = max_sessions;
   b->slots.reserve(max_sessions);
   for (int i = 0; i < max_sessions; ++i) b->slots.push_back(new BrokerSlot);
   const size_t S = (size_t)max_sessions;
-  const size_t sig_bytes = S * kBrokerStageSamples * channels * sizeof(float);
   int rc = [&]() -> int {
-    for (int p = 0; p < 2; ++p) {
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage[p]), sig_bytes, hipHostMallocDefault));
-      HIP_TRY(b->d_sig[p].reserve(sig_bytes));
-    }
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_meta), 5 * S * sizeof(uint32_t), hipHostMallocDefault));
-    HIP_TRY(b->d_meta.reserve(5 * S * sizeof(uint32_t)));
+    int r = b->fft.alloc(S, kBrokerStageSamples, channels);
+    if (r != PEAQ_OK) return r;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_meta), 7 * S * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(b->d_meta.reserve(7 * S * sizeof(uint32_t)));
     HIP_TRY(b->records.reserve(S * kBrokerMaxFrames * channels * kRecDoubles * sizeof(double)));
     HIP_TRY(b->state.reserve(S * sizeof(PairState)));
     HIP_TRY(b->result.reserve(sizeof(ResultRecord)));
     HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&b->staged, hipEventDisableTiming));
-    HIP_TRY(launch_state_init(b->state.as<PairState>(), 0, max_sessions, b->stream));
+    HIP_TRY(launch_state_init(b->state.as<PairState>(), b->advanced, max_sessions, b->stream));
+    if (b->advanced) {
+      r = b->fbs.alloc(S, kBrokerFbStageSamples, channels);
+      if (r != PEAQ_OK) return r;
+      const size_t n_signals = S * channels * 2;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_win), S * sizeof(FbPairWindow), hipHostMallocDefault));
+      HIP_TRY(b->d_win.reserve(S * sizeof(FbPairWindow)));
+      HIP_TRY(b->fb_records.reserve(S * kBrokerMaxBlocks * channels * kFbRecDoubles * sizeof(double)));
+      HIP_TRY(b->fbstate.reserve(n_signals * sizeof(FbSignalState)));
+      HIP_TRY(hipMemsetAsync(b->fbstate.p, 0, n_signals * sizeof(FbSignalState), b->stream));
+      HIP_TRY(b->hp_rows.reserve(n_signals * kBrokerRowStride * sizeof(double)));
+    }
     return PEAQ_OK;
   }();
   if (rc != PEAQ_OK) {
@@ -1135,14 +1260,17 @@ extern "C" void peaq_broker_destroy(peaq_broker* b) {
   (void)peaq_broker_stop(b);
   (void)hipSetDevice(b->ctx->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  for (int p = 0; p < 2; ++p) {
-    if (b->h_stage[p]) (void)hipHostFree(b->h_stage[p]);
-    b->d_sig[p].release();
-  }
+  b->fft.release();
+  b->fbs.release();
   if (b->h_meta) (void)hipHostFree(b->h_meta);
+  if (b->h_win) (void)hipHostFree(b->h_win);
   b->d_meta.release();
+  b->d_win.release();
   b->records.release();
+  b->fb_records.release();
   b->state.release();
+  b->fbstate.release();
+  b->hp_rows.release();
   b->result.release();
   if (b->staged) (void)hipEventDestroy(b->staged);
   if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -1158,13 +1286,16 @@ extern "C" int peaq_broker_open(peaq_broker* b, int* session_id) {
     std::lock_guard<std::mutex> lock(sl.mu);
     if (sl.open) continue;
     HIP_TRY(hipSetDevice(b->ctx->device));
-    HIP_TRY(launch_state_init(b->state.as<PairState>() + sid, 0, 1, b->stream));
+    HIP_TRY(launch_state_init(b->state.as<PairState>() + sid, b->advanced, 1, b->stream));
+    if (b->advanced)
+      HIP_TRY(hipMemsetAsync(b->fbstate.as<FbSignalState>() + (size_t)sid * b->channels * 2, 0,
+                             (size_t)b->channels * 2 * sizeof(FbSignalState), b->stream));
     sl.open = true;
-    sl.flush_requested = false;
+    sl.flush_requested = sl.fft_flushed = sl.fb_flushed = false;
     sl.pad[0] = PadFifo();
     sl.pad[1] = PadFifo();
-    sl.fft_pos[0] = sl.fft_pos[1] = 0;
-    sl.frames_done = 0;
+    sl.fft_pos[0] = sl.fft_pos[1] = sl.fb_pos[0] = sl.fb_pos[1] = 0;
+    sl.frames_done = sl.blocks_done = sl.fb_prev_blocks = 0;
     *session_id = sid;
     return PEAQ_OK;
   }
@@ -1213,6 +1344,7 @@ extern "C" int peaq_broker_flush(peaq_broker* b, int session_id) {
   std::lock_guard<std::mutex> lock(sl->mu);
   if (!sl->open) return fail(PEAQ_ERR_STATE, "peaq_broker_flush: session is not open");
   sl->flush_requested = true;
+  sl->fft_flushed = sl->fb_flushed = false;
   return PEAQ_OK;
 }
 
@@ -1222,11 +1354,16 @@ extern "C" int peaq_broker_tick(peaq_broker* b, unsigned* n_active) {
   return broker_tick_locked(b, n_active);
 }
 
-// true while the session has whole frames (or a requested flush) not yet launched
-static bool broker_slot_busy(BrokerSlot* sl) {
+// true while the session has whole frames / blocks (or a requested flush) not yet launched
+static bool broker_slot_busy(const peaq_broker* b, BrokerSlot* sl) {
   std::lock_guard<std::mutex> lock(sl->mu);
   const uint64_t av = std::min(sl->pad[0].total - sl->fft_pos[0], sl->pad[1].total - sl->fft_pos[1]);
-  return av >= (uint64_t)kFrame || sl->flush_requested;
+  if (av >= (uint64_t)kFrame || sl->flush_requested) return true;
+  if (b->advanced) {
+    const uint64_t avb = std::min(sl->pad[0].total - sl->fb_pos[0], sl->pad[1].total - sl->fb_pos[1]);
+    if (avb >= (uint64_t)kFbFrame) return true;
+  }
+  return false;
 }
 
 extern "C" int peaq_broker_results(peaq_broker* b, int session_id, peaq_result* out) {
@@ -1237,13 +1374,13 @@ extern "C" int peaq_broker_results(peaq_broker* b, int session_id, peaq_result* 
     std::lock_guard<std::mutex> lock(sl->mu);
     if (!sl->open) return fail(PEAQ_ERR_STATE, "peaq_broker_results: session is not open");
   }
-  while (broker_slot_busy(sl)) {
+  while (broker_slot_busy(b, sl)) {
     const int rc = broker_tick_locked(b, nullptr);
     if (rc != PEAQ_OK) return rc;
   }
   HIP_TRY(hipSetDevice(b->ctx->device));
-  HIP_TRY(launch_finalize(b->state.as<PairState>() + session_id, 0, b->channels, 1, b->result.as<ResultRecord>(),
-                          b->stream));
+  HIP_TRY(launch_finalize(b->state.as<PairState>() + session_id, b->advanced, b->channels, 1,
+                          b->result.as<ResultRecord>(), b->stream));
   HIP_TRY(hipMemcpyAsync(out, b->result.p, sizeof(peaq_result), hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
   return PEAQ_OK;

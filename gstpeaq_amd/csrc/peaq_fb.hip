@@ -77,32 +77,43 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
   const long long off = sig ? a.off_test : a.off_ref;
   const size_t row_len = a.hp_row_stride;
   double* __restrict__ rows = a.hp_scratch;
-  double* __restrict__ my_row = rows + (size_t)gg * row_len;
-  FbSignalState* __restrict__ st = a.fbstate + gg;
+  // where this signal's blocks of the launch start, how many there are, and where its state lives
+  unsigned blk0 = a.block0, origin = a.block_origin, prev_blocks = a.prev_blocks, nb_mine = 0, state_idx = gg;
+  bool first = a.first_launch;
+  if (a.windows) {
+    const FbPairWindow w = a.windows[pair];
+    blk0 = origin = w.block0;
+    prev_blocks = w.prev_blocks;
+    first = w.block0 == 0;
+    state_idx = (w.slot * a.channels + chan) * 2 + sig;
+    if (live) nb_mine = w.n_blocks;
+  } else if (live && n_blocks > a.block0) {
+    nb_mine = min(a.blocks_per_launch, n_blocks - a.block0);
+  }
+  double* __restrict__ my_row = rows + (size_t)state_idx * row_len;
+  FbSignalState* __restrict__ st = a.fbstate + state_idx;
 
-  // how many blocks of this launch exist for my pair
-  unsigned nb_mine = 0;
-  if (live && n_blocks > a.block0) nb_mine = min(a.blocks_per_launch, n_blocks - a.block0);
   unsigned nb_max = nb_mine;                         // wave-uniform loop bound
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) nb_max = max(nb_max, (unsigned)__shfl_xor((int)nb_max, d, 64));
 
   // history: the newest 1456 filtered samples of the previous launch sit at the row's tail
   if (nb_mine > 0) {
-    if (a.first_launch) {
+    if (first) {
       for (int i = 0; i < kFbRing; ++i) my_row[i] = 0.;
     } else {
-      const size_t tail = (size_t)a.prev_blocks * kFbFrame;
-      const double* __restrict__ prev_row = a.hp_prev ? a.hp_prev + (size_t)gg * row_len : my_row;
+      const size_t tail = (size_t)prev_blocks * kFbFrame;
+      const double* __restrict__ prev_row = a.hp_prev ? a.hp_prev + (size_t)state_idx * row_len : my_row;
       for (int i = 0; i < kFbRing; ++i) my_row[i] = prev_row[tail + i];
     }
   }
   HpWalk w{st->hp[0], st->hp[1], st->hp[2], st->hp[3], st->hp[4], st->hp[5]};
+  HpWalk fin = w;
 
   // samples are fetched 16 ahead of their use: the walk itself is a chain of dependent FP64
   // operations, the loads (one cache line per lane) must never be waited for
   auto fetch = [&](unsigned bl, int k, bool mine) -> float {
-    const long long s = (long long)(a.block0 + bl - a.block_origin) * kFbFrame + off + k;
+    const long long s = (long long)(blk0 + bl - origin) * kFbFrame + off + k;
     return (mine && s < (long long)n_sig) ? x[s * a.channels] : 0.f;   // zero padding: gstpeaq.c:733-738
   };
   float xq[16];
@@ -151,20 +162,24 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int src = r * 8 + (lane >> 3);
-        const unsigned gs = g0 + src;
-        const unsigned pair_s = gs / (2 * a.channels);
-        const unsigned nbs = gs < n_signals ? (a.n_blocks ? a.n_blocks[pair_s] : a.n_blocks_uniform) : 0;
-        if (gs < n_signals && a.block0 + bl < nbs)
-          rows[(size_t)gs * row_len + kFbRing + (size_t)bl * kFbFrame + k0 + (lane & 7)] = tile[src][lane & 7];
+        // the source lane's row and block count (its own mapping under broker launches)
+        const unsigned row_s = (unsigned)__shfl((int)state_idx, src, 64);
+        const unsigned nb_s = (unsigned)__shfl((int)nb_mine, src, 64);
+        if (bl < nb_s)
+          rows[(size_t)row_s * row_len + kFbRing + (size_t)bl * kFbFrame + k0 + (lane & 7)] = tile[src][lane & 7];
       }
       wave_lds_fence();
     }
     if (mine && sig == 0)
       a.records[((size_t)(pair * a.blocks_per_launch + bl) * a.channels + chan) * kFbRecDoubles + kFbRecFlags] =
           (double)above;
+    // the wave walks on (with zero input) until its longest signal is done: keep the state as it
+    // was after this signal's own last block
+    if (bl + 1 == nb_mine) fin = w;
   }
   if (nb_mine > 0) {
-    st->hp[0] = w.x1; st->hp[1] = w.x2; st->hp[2] = w.y1a; st->hp[3] = w.y2a; st->hp[4] = w.y1b; st->hp[5] = w.y2b;
+    st->hp[0] = fin.x1; st->hp[1] = fin.x2; st->hp[2] = fin.y1a; st->hp[3] = fin.y2a; st->hp[4] = fin.y1b;
+    st->hp[5] = fin.y2b;
   }
 }
 
@@ -349,15 +364,22 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
   const int sig = g & 1;
   const int chan = (g >> 1) % a.channels;
   const unsigned pair = g / (2 * a.channels);
-  const unsigned n_blocks = a.n_blocks ? a.n_blocks[pair] : a.n_blocks_uniform;
-  if (n_blocks <= a.block0) return;
-  const unsigned nb_mine = min(a.blocks_per_launch, n_blocks - a.block0);
+  unsigned nb_mine, state_idx = g;
+  if (a.windows) {                                   // broker launch: this session's own window and state
+    const FbPairWindow w = a.windows[pair];
+    nb_mine = w.n_blocks;
+    state_idx = (w.slot * a.channels + chan) * 2 + sig;
+  } else {
+    const unsigned n_blocks = a.n_blocks ? a.n_blocks[pair] : a.n_blocks_uniform;
+    nb_mine = n_blocks > a.block0 ? min(a.blocks_per_launch, n_blocks - a.block0) : 0;
+  }
+  if (nb_mine == 0) return;
   const BandTables* __restrict__ bt = a.bands;
   const FbTables* __restrict__ fb = a.fb;
   const size_t row_len = a.hp_row_stride;
   const size_t row_valid = (size_t)kFbRing + (size_t)a.blocks_per_launch * kFbFrame;
-  const double* __restrict__ row = a.hp_scratch + (size_t)g * row_len;
-  FbSignalState* __restrict__ st = a.fbstate + g;
+  const double* __restrict__ row = a.hp_scratch + (size_t)state_idx * row_len;
+  FbSignalState* __restrict__ st = a.fbstate + state_idx;
 
   // recurrent state -> LDS / registers
   if (tid < kFbBands) {

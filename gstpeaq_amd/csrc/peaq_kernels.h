@@ -64,6 +64,14 @@ hipError_t launch_finalize(const PairState* state, int advanced, int channels, u
 hipError_t launch_state_init(PairState* state, int advanced, unsigned n_pairs, hipStream_t stream);
 
 // ---- advanced mode: filter-bank ear model ------------------------------------------
+// Broker launches: "pair" p of the launch is a live session at its own position in its stream.
+struct FbPairWindow {
+  uint32_t block0;              // index of the session's first block of this launch (0 = its very first block)
+  uint32_t n_blocks;            // blocks of this session in this launch
+  uint32_t prev_blocks;         // n_blocks of the session's previous launch (where its history tail sits)
+  uint32_t slot;                // index of the session's filter state, rows and PairState
+};
+
 struct FbFrontArgs {
   const float* ref;
   const float* test;
@@ -88,6 +96,7 @@ struct FbFrontArgs {
   const double* hp_prev;        // rows of the previous launch (history source); nullptr: hp_scratch itself
   size_t hp_row_stride;
   double* records;              // [pair][block - block0][channel][kFbRecDoubles]
+  const FbPairWindow* windows;  // broker launches (see above); nullptr: the uniform fields apply, slot = pair
 };
 hipError_t launch_fb_frontend(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream);   // high-pass + filter bank
 hipError_t launch_fb_hp(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream);
@@ -101,6 +110,7 @@ struct FbBackendArgs {
   int channels;
   const BandTables* bands;
   PairState* state;
+  const FbPairWindow* windows;  // broker launches
 };
 hipError_t launch_fb_backend(const FbBackendArgs& a, unsigned n_pairs, hipStream_t stream);
 

@@ -88,30 +88,31 @@ shared_context (void)
 
 /* PEAQ_AMD_BROKER=<max sessions>: a process that hosts many `peaq` elements lets ONE broker run
  * the frames of all of them as one batched launch per tick (include/peaq_amd.h, "broker").  One
- * broker per channel count, basic model at the default playback level; any other element keeps
- * its own session. */
+ * broker per (version, channel count) at the default playback level; an element with another
+ * level keeps its own session. */
 static peaq_broker *
-shared_broker (gint channels)
+shared_broker (gboolean advanced, gint channels)
 {
   static GMutex lock;
-  static peaq_broker *brokers[3] = { NULL, NULL, NULL };
+  static peaq_broker *brokers[2][3] = { {NULL, NULL, NULL}, {NULL, NULL, NULL} };
   const gchar *max = g_getenv ("PEAQ_AMD_BROKER");
+  const gint adv = advanced ? 1 : 0;
   peaq_broker *b = NULL;
   if (!max || atoi (max) <= 0 || channels < 1 || channels > 2)
     return NULL;
   g_mutex_lock (&lock);
-  if (!brokers[channels]) {
+  if (!brokers[adv][channels]) {
     peaq_ctx *ctx = shared_context ();
     const gchar *period = g_getenv ("PEAQ_AMD_BROKER_PERIOD_US");
-    if (ctx && peaq_broker_create (ctx, channels, 92., atoi (max), &brokers[channels]) == PEAQ_OK) {
-      if (peaq_broker_start (brokers[channels], period ? (unsigned) atoi (period) : 0) != PEAQ_OK)
+    if (ctx && peaq_broker_create (ctx, adv, channels, 92., atoi (max), &brokers[adv][channels]) == PEAQ_OK) {
+      if (peaq_broker_start (brokers[adv][channels], period ? (unsigned) atoi (period) : 0) != PEAQ_OK)
         GST_WARNING ("libpeaq_amd: %s", peaq_last_error ());
     } else {
       GST_WARNING ("libpeaq_amd: no broker (%s), using one session per element", peaq_last_error ());
-      brokers[channels] = NULL;
+      brokers[adv][channels] = NULL;
     }
   }
-  b = brokers[channels];
+  b = brokers[adv][channels];
   g_mutex_unlock (&lock);
   return b;
 }
@@ -136,8 +137,8 @@ renew_session (GstPeaqAmd * self)
   drop_session (self);
   if (self->channels <= 0)
     return TRUE;
-  if (!self->advanced && self->playback_level == 92.) {
-    peaq_broker *b = shared_broker (self->channels);
+  if (self->playback_level == 92.) {
+    peaq_broker *b = shared_broker (self->advanced, self->channels);
     if (b && peaq_broker_open (b, &self->broker_sid) == PEAQ_OK) {
       self->broker = b;
       return TRUE;

@@ -113,7 +113,7 @@ int peaq_session_reset (peaq_session *s);
  * push only queues on the host, and each tick runs the frames that became
  * ready in all sessions as ONE batched front-end + back-end launch.  The
  * result of a session is identical to that of a peaq_session fed the same
- * stream.  Basic model only.  All entry points are thread-safe. */
+ * stream (basic and advanced version).  All entry points are thread-safe. */
 typedef struct peaq_broker peaq_broker;
 typedef struct peaq_broker_stats_t {
   uint64_t ticks;        /* ticks executed (including idle ones)             */
@@ -122,8 +122,8 @@ typedef struct peaq_broker_stats_t {
   uint32_t max_active;   /* most sessions served by a single launch          */
   uint32_t worker_failed;/* the tick thread stopped on a device error        */
 } peaq_broker_stats_t;
-int  peaq_broker_create  (peaq_ctx *ctx, int channels, double playback_level_db, int max_sessions,
-                          peaq_broker **out);
+int  peaq_broker_create  (peaq_ctx *ctx, int advanced, int channels, double playback_level_db,
+                          int max_sessions, peaq_broker **out);
 void peaq_broker_destroy (peaq_broker *b);
 int  peaq_broker_open    (peaq_broker *b, int *session_id);            /* gst_peaq_init / READY->PAUSED      */
 int  peaq_broker_close   (peaq_broker *b, int session_id);             /* finalize                           */

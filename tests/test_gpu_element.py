@@ -115,3 +115,14 @@ def test_many_elements_share_the_broker():
     assert out.returncode == 0, out.stderr[-2000:]
     odgs = sorted(l.split()[3] for l in out.stdout.splitlines() if l.startswith("Objective Difference Grade:"))
     assert odgs == sorted(["0.171"] * (n // 2) + ["-2.007"] * (n // 2)), out.stdout[-1500:]
+    # the advanced version goes through its own broker (saw vs triangle: -3.612, as test_element_advanced_mode)
+    args = []
+    for i in range(4):
+        args += ["audiotestsrc", f"name=s{i}", "num-buffers=128", "wave=saw", "freq=440",
+                 "audiotestsrc", f"name=r{i}", "num-buffers=128", "wave=triangle", "freq=440",
+                 "peaq", f"name=p{i}", "advanced=true", f"s{i}.src!p{i}.ref", f"r{i}.src!p{i}.test"]
+    out = subprocess.run(["gst-launch-1.0", "-q", f"--gst-plugin-load={gst_env.PLUGIN}", *args],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    odgs = [l.split()[3] for l in out.stdout.splitlines() if l.startswith("Objective Difference Grade:")]
+    assert odgs == ["-3.612"] * 4, out.stdout[-1500:]

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--feeders", type=int, default=8)
     ap.add_argument("--period-us", type=int, default=2000)
     ap.add_argument("--no-broker", action="store_true", help="one peaq_session per stream instead")
+    ap.add_argument("--advanced", action="store_true")
     args = ap.parse_args()
     import gstpeaq_amd
     import synth_np
@@ -33,9 +34,9 @@ def main():
     # 16 distinct seeded pairs, reused round-robin (the host generator is slow)
     pairs = [synth_np.pair(1 + i, 2, n) for i in range(16)]
     if args.no_broker:
-        sessions = [gstpeaq_amd.Session(ctx, False, 2) for _ in range(args.sessions)]
+        sessions = [gstpeaq_amd.Session(ctx, args.advanced, 2) for _ in range(args.sessions)]
     else:
-        b = gstpeaq_amd.Broker(ctx, 2, args.sessions)
+        b = gstpeaq_amd.Broker(ctx, 2, args.sessions, advanced=args.advanced)
         sids = [b.open() for _ in range(args.sessions)]
         b.start(args.period_us)
     results = [None] * args.sessions
@@ -71,7 +72,7 @@ def main():
     frames = sum(r["frames"] for r in results)
     line = dict(sessions=args.sessions, seconds=args.seconds, buffer=args.buffer, wall_s=dt,
                 frame_pairs_per_s=frames / dt, realtime_streams=args.sessions * args.seconds / dt,
-                mode="one session per stream" if args.no_broker else "broker",
+                mode=("one session per stream" if args.no_broker else "broker") + (", advanced" if args.advanced else ", basic"),
                 odg_mean=float(np.mean([r["odg"] for r in results])))
     if not args.no_broker:
         line.update(b.stats())
