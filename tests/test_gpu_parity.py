@@ -202,3 +202,23 @@ def test_session_streaming_equals_batch(gpu, advanced):
     assert abs(got["odg"] - whole["odg"]) <= (1e-10 if advanced else 0)
     assert s.results()["odg"] == got["odg"]            # idempotent
     s.close()
+
+
+@pytest.mark.parametrize("advanced", [0, 1])
+def test_empty_and_tiny_pairs_inside_a_batch(gpu, advanced):
+    """an element that reaches EOS without data reports NaN (empty accumulators, movaccum.c:438-481);
+    one that got a single sample runs exactly the flush frame / block (gstpeaq.c:716-745)"""
+    normal = case_defs.make_inputs(dict(kind="synth", seed=5, channels=2, n=50000))
+    empty = (np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32))
+    one = (normal[0][:1].copy(), normal[1][:1].copy())
+    ref_only = (normal[0][:3000].copy(), np.zeros((0, 2), np.float32))     # the test pad never delivered
+    got = gpu.run_batch([normal, empty, one, ref_only], advanced, 2)
+    alone = gpu.run_batch([normal], advanced, 2)[0]
+    np.testing.assert_allclose(got[0]["movs"], alone["movs"], rtol=1e-9 if advanced else 0, atol=0)
+    assert got[1]["frames"] == 0 and got[1]["fb_blocks"] == 0 and np.isnan(got[1]["odg"])
+    for g, (r, t) in ((got[1], empty), (got[2], one), (got[3], ref_only)):
+        e = orc.run_pair(advanced, r, t)
+        assert g["frames"] == e["frames"]                # one flush frame if anything was delivered
+        assert np.array_equal(np.isnan(g["movs"]), np.isnan(e["movs"][:len(g["movs"])]))
+        fin = ~np.isnan(g["movs"])
+        np.testing.assert_allclose(g["movs"][fin], e["movs"][:len(g["movs"])][fin], rtol=1e-7, atol=1e-9)
