@@ -12,6 +12,7 @@
  *   ref_harness synth ADV CH SEED NSAMPLES        include/peaq_synth.h pair
  *   ref_harness launch ADV "<gst-launch fragment feeding peaq.ref / peaq.test>"
  *   ref_harness time ADV CH SEED0 NPAIRS NSAMPLES  wall-clock of the element on NPAIRS synth pairs
+ *   (environment REF_PLAYBACK_LEVEL=<dB> sets the element's playback_level in pair / synth / launch)
  *   ref_harness fftear BANDS FILE.f32             per-frame ear-model dumps (mono, hop 1024)
  *   ref_harness fbear FILE.f32                    per-block filter-bank dumps (mono, 192)
  * Output: one JSON object on stdout.
@@ -59,6 +60,8 @@ run_pipeline (int advanced, const char *desc)
   }
   peaq_el = gst_bin_get_by_name (GST_BIN (pipe), "peaq");
   g_object_set (peaq_el, "advanced", advanced, "console-output", FALSE, NULL);
+  if (getenv ("REF_PLAYBACK_LEVEL"))            /* the element's playback_level property (gstpeaq.c:273-281) */
+    g_object_set (peaq_el, "playback_level", atof (getenv ("REF_PLAYBACK_LEVEL")), NULL);
   gst_element_set_state (pipe, GST_STATE_PLAYING);
   bus = gst_element_get_bus (pipe);
   msg = gst_bus_timed_pop_filtered (bus, GST_CLOCK_TIME_NONE, GST_MESSAGE_EOS | GST_MESSAGE_ERROR);

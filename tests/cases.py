@@ -66,6 +66,16 @@ def e2e_cases():
     return cases
 
 
+def level_cases():
+    """playback_level other than the default (the level enters both ear models' input scaling)"""
+    cases = []
+    for adv in (0, 1):
+        for level, seed in ((60.0, 3), (75.5, 4), (105.0, 5), (130.0, 6)):
+            cases.append(dict(name=f"synth_s{seed}_L{level:g}", kind="synth", seed=seed, channels=2, n=96000,
+                              level=level, advanced=adv))
+    return cases
+
+
 def stage_inputs():
     """Mono signals for the stage-level dumps (ear models)."""
     ref, test = synth_np.pair(5, 1, 8192)

@@ -222,3 +222,34 @@ def test_empty_and_tiny_pairs_inside_a_batch(gpu, advanced):
         assert np.array_equal(np.isnan(g["movs"]), np.isnan(e["movs"][:len(g["movs"])]))
         fin = ~np.isnan(g["movs"])
         np.testing.assert_allclose(g["movs"][fin], e["movs"][:len(g["movs"])][fin], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("advanced", [0, 1])
+def test_playback_level_matches_reference_goldens(gpu, advanced):
+    """playback_level 60 .. 130 dB SPL through batch run, session and broker vs the real element"""
+    import json
+    import torch
+    import gstpeaq_amd
+    recs = [r for r in json.loads((gpu.GOLD / "ref_e2e_level.json").read_text()) if r["case"]["advanced"] == advanced]
+    assert len(recs) == 4
+    for rec in recs:
+        case = rec["case"]
+        ref, test = case_defs.make_inputs(case)
+        got = gstpeaq_amd.batch_run(gpu.ctx(), advanced, torch.from_numpy(ref[None]).cuda(),
+                                    torch.from_numpy(test[None]).cuda(), playback_level=case["level"])[0]
+        gpu.compare_result(got, rec, rtol=1e-7, atol=1e-9, odg_atol=1e-6)
+        s = gstpeaq_amd.Session(gpu.ctx(), advanced, case["channels"], playback_level=case["level"])
+        s.push_ref(ref)
+        s.push_test(test)
+        s.flush()
+        gpu.compare_result(s.results(), rec, rtol=1e-7, atol=1e-9, odg_atol=1e-6)
+        s.close()
+        b = gstpeaq_amd.Broker(gpu.ctx(), case["channels"], 2, playback_level=case["level"], advanced=advanced)
+        sid = b.open()
+        b.push(sid, 0, ref)
+        b.push(sid, 1, test)
+        b.flush(sid)
+        gpu.compare_result(b.results(sid), rec, rtol=1e-7, atol=1e-9, odg_atol=1e-6)
+        b.close()
+    with pytest.raises(gstpeaq_amd.PeaqError):                     # property range 0..130 (gstpeaq.c:275-281)
+        gstpeaq_amd.Session(gpu.ctx(), advanced, 2, playback_level=131.0)

@@ -7,6 +7,7 @@
 CPU-only; no GPU, no /root/reference needed."""
 import json
 import math
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -202,3 +203,19 @@ def test_streaming_chunking_is_irrelevant():
     s.flush()
     got = s.results()
     assert np.array_equal(got["movs"], whole["movs"]) and got["odg"] == whole["odg"]
+
+
+def _level_recs():
+    return json.loads((Path(__file__).parent / "golden" / "ref_e2e_level.json").read_text())
+
+
+@pytest.mark.parametrize("idx", range(len(_level_recs())),
+                         ids=[f"{r['case']['name']}-{'adv' if r['case']['advanced'] else 'basic'}" for r in _level_recs()])
+def test_playback_level_matches_reference_element(idx):
+    """the playback_level property (gstpeaq.c:273-281) scales the input of both ear models
+    (fftearmodel.c:305-314, fbearmodel.c:249-254); goldens from the real element at 60..130 dB"""
+    rec = _level_recs()[idx]
+    case = rec["case"]
+    ref, test = case_defs.make_inputs(case)
+    got = orc.run_pair(case["advanced"], ref, test, level=case["level"])
+    check_against_reference(got, rec, rtol=1e-9, atol=1e-9)

@@ -34,8 +34,11 @@ def _fix(v):
             for x in v]
 
 
-def run_harness(*args):
-    out = subprocess.run([str(HARNESS), *map(str, args)], check=True, capture_output=True, text=True).stdout
+def run_harness(*args, level=None):
+    env = dict(os.environ)
+    if level is not None:
+        env["REF_PLAYBACK_LEVEL"] = repr(float(level))
+    out = subprocess.run([str(HARNESS), *map(str, args)], check=True, capture_output=True, text=True, env=env).stdout
     return json.loads(out)
 
 
@@ -79,6 +82,22 @@ def e2e():
             results.append(rec)
             print(f"{case['name']:28s} adv={case['advanced']} frames={r['frames']:4d} odg={r['odg'][0]}")
     (GOLD / "ref_e2e.json").write_text(json.dumps(results, indent=0))
+
+
+def e2e_levels():
+    """the playback_level property (gstpeaq.c:273-281): other listening levels than the default 92 dB SPL"""
+    results = []
+    with tempfile.TemporaryDirectory() as td:
+        for case in case_defs.level_cases():
+            ref, test = case_defs.make_inputs(case)
+            rp, tp = Path(td) / "r.f32", Path(td) / "t.f32"
+            ref.astype("<f4").tofile(rp)
+            test.astype("<f4").tofile(tp)
+            r = run_harness("pair", case["advanced"], case["channels"], rp, tp, level=case["level"])
+            results.append(dict(case=case, frames=r["frames"], fb_frames=r["fb_frames"], movs=r["movs"], di=r["di"][0],
+                                odg=r["odg"][0], totalsnr=r["totalsnr"][0]))
+            print(f"{case['name']:28s} adv={case['advanced']} level={case['level']} odg={r['odg'][0]}")
+    (GOLD / "ref_e2e_level.json").write_text(json.dumps(results, indent=0))
 
 
 def stages():
@@ -129,7 +148,12 @@ def main():
     tables()
     stages()
     e2e()
+    e2e_levels()
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "levels":      # only the playback-level cases
+        subprocess.run(["make", "-C", str(ROOT / "oracle"), "ref"], check=True)
+        e2e_levels()
+    else:
+        main()
