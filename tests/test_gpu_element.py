@@ -126,3 +126,16 @@ def test_many_elements_share_the_broker():
     assert out.returncode == 0, out.stderr[-2000:]
     odgs = [l.split()[3] for l in out.stdout.splitlines() if l.startswith("Objective Difference Grade:")]
     assert odgs == ["-3.612"] * 4, out.stdout[-1500:]
+
+
+def test_element_playback_level_property():
+    """playback_level (gstpeaq.c:273-281) reaches the engine: saw vs triangle at 75.5 dB SPL; the
+    printed ODG equals the oracle's for the same audiotestsrc samples"""
+    import synth_np
+    out = launch("audiotestsrc", "name=src0", "num-buffers=64", "wave=saw", "freq=440",
+                 "audiotestsrc", "name=src1", "num-buffers=64", "wave=triangle", "freq=440",
+                 "peaq", "name=peaq", "playback_level=75.5", "src0.src!peaq.ref", "src1.src!peaq.test")
+    n = 64 * 1024
+    e = orc.run_pair(0, synth_np.audiotestsrc("saw", n), synth_np.audiotestsrc("triangle", n), level=75.5)
+    assert odg_of(out) == "%.3f" % e["odg"]
+    assert odg_of(out) != "-2.007"                     # not the default level's answer
