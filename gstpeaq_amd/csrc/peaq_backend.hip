@@ -310,7 +310,7 @@ __device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, 
       const double sref = thres_fac * mod_ref[s] + s0;
       const double stest = thres_fac * mod_test[s] + s0;
       const double ethres = bt.internal_noise(bl.band(s));
-      const double beta = exp(-alpha * (e_test[s] - e_ref[s]) / e_ref[s]);
+      const double beta = exp_fast(-alpha * (e_test[s] - e_ref[s]) / e_ref[s]);
       nl += pow_pos(ethres / stest, 0.23) *
             (pow_pos(1. + fmax(stest * e_test[s] - sref * e_ref[s], 0.) / (ethres + sref * e_ref[s] * beta), 0.23) - 1.);
     }
@@ -497,8 +497,8 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
       for (int s = 0; s < SLOTS; ++s) {
         double pc = 0., qc = 0.;
         if (bl.valid(s)) {
-          const double er_db = 10. * log10(er[s]);
-          const double et_db = 10. * log10(et[s]);
+          const double er_db = (10. * kInvLn10) * log_pos(er[s]);     // 10 log10: excitations are > 0
+          const double et_db = (10. * kInvLn10) * log_pos(et[s]);
           const double l = 0.3 * fmax(er_db, et_db) + 0.7 * et_db;
           const double l2 = l * l;
           const double sd = l > 0. ? 5.95072 * pow_pos(6.39468 / l, 1.71332) + 9.01033e-11 * l2 * l2 +
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
           const double e = er_db - et_db;
           const double x = e / sd, x2 = x * x;
           const double xb = er_db > et_db ? x2 * x2 : x2 * x2 * x2;   // (e/s)^b, b = 4 or 6
-          pc = 1. - exp2(-xb);                                        // 1 - 0.5^((e/s)^b)
+          pc = 1. - exp_fast(-kLn2 * xb);                             // 1 - 0.5^((e/s)^b)
           qc = fabs(trunc(e)) / sd;
         }
         sh.pc[chan][bl.band(s)] = pc;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
         route(MB_NMR, nsum, 1.);                                    // MODE_AVG_LOG
         route(MB_RELDIST, nmax > 1.41253754462275 ? 1. : 0., 1.);
       } else {
-        route(MA_SEGNMR, 10. * log10(nsum), 1.);                    // MODE_AVG
+        route(MA_SEGNMR, (10. * kInvLn10) * log_pos(nsum), 1.);     // 10 log10, MODE_AVG; nsum > 0 (floored bands)
       }
     }
     // ---- error harmonic structure (movs.c:1374-1381,1442) ------------------------------

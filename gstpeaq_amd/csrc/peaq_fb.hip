@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       const int b = wave_band(wv, i);
       // pow(DIST, s), s = max(4, 24 + 230/fc - 0.2 L), L = 10 log10 |A|^2 (fbearmodel.c:329-333), as
       // exp(min(4 ln DIST, ln DIST (24 + 230/fc) - 2 ln DIST / ln 10 * ln |A|^2))  (ln DIST < 0)
-      const double dist_s = exp(fmin(4. * kLnDist, c0[i] + kC1 * log(re[i] * re[i] + im[i] * im[i])));
+      const double dist_s = exp_fast(fmin(4. * kLnDist, c0[i] + kC1 * log_nonneg(re[i] * re[i] + im[i] * im[i])));
       double v = kSlopeA * dist_s, m = 1. - kSlopeA;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {

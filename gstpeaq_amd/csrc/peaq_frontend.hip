@@ -405,11 +405,11 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     if (b < NB) {
       const double pp = ppx[b] + bt->internal_noise[b];                                            // :483-485
       // Kabal (23)-(24); fftearmodel.c:649-656.  a^y evaluated as exp(y ln a).
-      const double ln_a = bt->ln_aUC[b] + bt->dz02 * log(pp);
-      const double a_uce = exp(ln_a);
-      const double g_iu = (1. - exp((double)(NB - b) * ln_a)) / (1. - a_uce);
+      const double ln_a = bt->ln_aUC[b] + bt->dz02 * log_pos(pp);
+      const double a_uce = exp_fast(ln_a);
+      const double g_iu = (1. - exp_fast((double)(NB - b) * ln_a)) / (1. - a_uce);
       const double en = pp / (bt->gIL[b] + g_iu - 1.);
-      ae[s] = exp(0.4 * ln_a);
+      ae[s] = exp_fast(0.4 * ln_a);
       ene[s] = pow_pos(en, 0.4);
     } else {
       ae[s] = 0.;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
   for (int j = 0; j < 4; ++j) {
     const int k = 256 * sig + lane + 64 * j;
     const double fr = pw_ref[k], ft = pw_test[k];
-    dlog[k] = (fr == 0. && ft == 0.) ? 0. : log(ft / fr);
+    dlog[k] = (fr == 0. && ft == 0.) ? 0. : log_nonneg(ft / fr);   // +-inf when one side is digital silence
   }
   __syncthreads();
   // ---- part 2: c[l] = sum_{k<256} d[k] d[k+l]  (the reference evaluates the same sums through

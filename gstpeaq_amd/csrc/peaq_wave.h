@@ -83,11 +83,81 @@ __device__ __forceinline__ int wave_or_i(int v) {
   return v;
 }
 
-// x^y for x > 0 as exp(y ln x).  OCML's pow() spends ~250 instructions on a correctly
-// rounded result and on special cases that cannot occur here (the arguments are positive
-// pattern energies); exp(y*log(x)) is ~180 with a relative error of |y ln x| ulp -- a few
-// 1e-15 at most for the ranges of this model, against a parity bar of 1e-7.
-__device__ __forceinline__ double pow_pos(double x, double y) { return exp(y * log(x)); }
+// ---- logarithm and exponential for this model ------------------------------------------
+// OCML's log() and exp() are correctly rounded over the whole double range at ~110 and ~54
+// instructions; the model calls them a few times per band and frame, which made them a fifth of
+// the front end's and half of the back end's instruction count.  The versions below (~33 / ~22
+// instructions) are accurate to about 1 ulp on what the model feeds them -- finite positive
+// arguments for the logarithm -- against a parity bar of 1e-7 (tools/check_math.hip measures them
+// against OCML on the GPU).
+
+// ln x for finite x > 0 (subnormals included).  x = m 2^e with m in [sqrt(1/2), sqrt(2));
+// ln m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716: odd series up to s^19 (truncation
+// < 2e-17 relative); e ln 2 is added as a 32-bit high part (exact product) plus a low part.
+__device__ __forceinline__ double log_pos(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);         // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool low = m < 0.70710678118654752440;
+  m = low ? m + m : m;
+  e = low ? e - 1 : e;
+  const double num = m - 1., den = m + 1.;           // both exact
+  double r = __builtin_amdgcn_rcp(den);              // den in [1.7, 2.42): two Newton steps, then
+  r = fma(fma(-den, r, 1.), r, r);                   // the quotient with one residual correction
+  r = fma(fma(-den, r, 1.), r, r);
+  double s = num * r;
+  s = fma(fma(-den, s, num), r, s);
+  const double z = s * s;
+  double p = 1. / 19;
+  p = fma(p, z, 1. / 17);
+  p = fma(p, z, 1. / 15);
+  p = fma(p, z, 1. / 13);
+  p = fma(p, z, 1. / 11);
+  p = fma(p, z, 1. / 9);
+  p = fma(p, z, 1. / 7);
+  p = fma(p, z, 1. / 5);
+  p = fma(p, z, 1. / 3);
+  const double t = s + s;
+  const double lm = fma(t * z, p, t);                // 2 s (1 + z P(z))
+  const double ef = (double)e;
+  return fma(ef, 6.93147180369123816490e-01, fma(ef, 1.90821492927058770002e-10, lm));
+}
+
+// the same for any x >= 0 or NaN: ln 0 = -inf, ln inf = inf (digital silence reaches the
+// logarithms of the error-harmonic-structure and of the filter-bank slope computation)
+__device__ __forceinline__ double log_nonneg(double x) {
+  const double l = log_pos(x);
+  return x == 0. ? -__builtin_inf() : (x == __builtin_inf() ? __builtin_inf() : l);
+}
+
+// e^x for any finite x or -inf (underflows to 0, overflows to inf through ldexp).
+// x = n ln 2 + r, |r| <= 0.3466; e^r as its Taylor polynomial of degree 12 (truncation 1.7e-16).
+__device__ __forceinline__ double exp_fast(double x) {
+  x = fmin(fmax(x, -1000.), 1000.);
+  const double n = __builtin_rint(x * 1.44269504088896338700e+00);
+  double r = fma(-n, 6.93147180369123816490e-01, x);
+  r = fma(-n, 1.90821492927058770002e-10, r);
+  double p = 1. / 479001600.;
+  p = fma(p, r, 1. / 39916800.);
+  p = fma(p, r, 1. / 3628800.);
+  p = fma(p, r, 1. / 362880.);
+  p = fma(p, r, 1. / 40320.);
+  p = fma(p, r, 1. / 5040.);
+  p = fma(p, r, 1. / 720.);
+  p = fma(p, r, 1. / 120.);
+  p = fma(p, r, 1. / 24.);
+  p = fma(p, r, 1. / 6.);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.);
+  p = fma(p, r, 1.);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
+constexpr double kInvLn10 = 0.43429448190325182765;   // log10 x = ln x / ln 10
+constexpr double kLn2 = 0.69314718055994530942;       // 2^x = e^(x ln 2)
+
+// x^y for x > 0 as exp(y ln x): relative error about |y ln x| ulp -- a few 1e-15 at most for the
+// ranges of this model.
+__device__ __forceinline__ double pow_pos(double x, double y) { return exp_fast(y * log_pos(x)); }
 
 // LDS traffic of ONE wave is executed in program order by the hardware; this
 // only stops the compiler from moving LDS accesses across the point.

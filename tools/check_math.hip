@@ -1,0 +1,84 @@
+// tools/check_math.hip -- accuracy of log_pos / log_nonneg / exp_fast / pow_pos (peaq_wave.h)
+// against OCML's correctly rounded log / exp / pow, measured ON the GPU.
+//   hipcc -O3 --offload-arch=gfx950 -I gstpeaq_amd/csrc tools/check_math.hip -o /tmp/check_math && /tmp/check_math
+// prints the worst error in ulp over 2^24 arguments per function (log-uniform over the ranges the
+// model produces and beyond) and checks the special values.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "peaq_wave.h"
+
+using namespace peaq;
+
+__device__ double ulp_err(double got, double want) {
+  if (got == want) return 0.;
+  if (isnan(got) || isnan(want) || isinf(got) || isinf(want)) return 1e300;
+  int e;
+  frexp(want, &e);
+  return fabs(got - want) / ldexp(1., e - 53 < -1074 ? -1074 : e - 53);   // subnormal results: ulp = 2^-1074
+}
+__device__ double u01(uint64_t i, uint64_t salt) {   // splitmix64 -> [0, 1)
+  uint64_t z = (i + salt) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (double)(z >> 11) * (1. / 9007199254740992.);
+}
+__global__ void sweep(double* worst) {   // worst[0] log, [1] exp, [2] pow, [3] log near 1
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double w0, w1, w2, w3;
+  {
+    const double x = exp2(u01(i, 1) * 2098. - 1074.);               // every finite positive magnitude
+    w0 = ulp_err(log_pos(x), log(x));
+    const double y = 1. + (u01(i, 2) - 0.5) * exp2(-u01(i, 3) * 50.);   // around 1, down to 1 +- 2^-51
+    w3 = ulp_err(log_pos(y), log(y));
+  }
+  {
+    const double x = (u01(i, 4) - 0.5) * 1480.;                     // the whole finite range of exp
+    w1 = ulp_err(exp_fast(x), exp(x));
+  }
+  {
+    const double x = exp2(u01(i, 5) * 120. - 60.), y = u01(i, 6) * 3.;   // 1e-18 .. 1e18, exponents 0 .. 3
+    w2 = ulp_err(pow_pos(x, y), pow(x, y));
+  }
+  double w[4] = {w0, w1, w2, w3};
+  for (int k = 0; k < 4; ++k) {
+    double v = w[k];
+    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(worst + k), __double_as_longlong(v));
+  }
+}
+__global__ void specials(double* out) {
+  out[0] = log_nonneg(0.);
+  out[1] = log_nonneg(__builtin_inf());
+  out[2] = log_nonneg(__builtin_nan(""));
+  out[3] = log_nonneg(4.9406564584124654e-324);
+  out[4] = exp_fast(-__builtin_inf());
+  out[5] = exp_fast(-800.);
+  out[6] = exp_fast(800.);
+  out[7] = exp_fast(0.);
+  out[8] = log_pos(1.);
+}
+int main() {
+  double *d_w, *d_s, w[4], s[9];
+  if (hipMalloc(&d_w, sizeof w) != hipSuccess || hipMalloc(&d_s, sizeof s) != hipSuccess ||
+      hipMemset(d_w, 0, sizeof w) != hipSuccess)
+    return 2;
+  hipLaunchKernelGGL(sweep, dim3(1 << 16), dim3(256), 0, 0, d_w);
+  hipLaunchKernelGGL(specials, dim3(1), dim3(1), 0, 0, d_s);
+  if (hipMemcpy(w, d_w, sizeof w, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(s, d_s, sizeof s, hipMemcpyDeviceToHost) != hipSuccess)
+    return 2;
+  printf("{\"n_per_function\": %d, \"log_pos_max_ulp\": %.3f, \"log_pos_near_1_max_ulp\": %.3f, \"exp_fast_max_ulp\": %.3f, "
+         "\"pow_pos_max_ulp\": %.3f, ", 1 << 24, w[0], w[3], w[1], w[2]);
+  printf("\"log_nonneg(0)\": \"%g\", \"log_nonneg(inf)\": \"%g\", \"log_nonneg(nan)\": \"%g\", \"log_nonneg(denorm_min)\": %.17g, "
+         "\"exp_fast(-inf)\": %g, \"exp_fast(-800)\": %g, \"exp_fast(800)\": \"%g\", \"exp_fast(0)\": %.17g, \"log_pos(1)\": %g}\n",
+         s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
+  const bool ok = w[0] < 2.5 && w[3] < 2.5 && w[1] < 2.5 && std::isinf(s[0]) && s[0] < 0 && std::isinf(s[1]) && std::isnan(s[2]) &&
+                  s[4] == 0. && s[5] == 0. && std::isinf(s[6]) && s[7] == 1. && s[8] == 0.;
+  return ok ? 0 : 1;
+}
