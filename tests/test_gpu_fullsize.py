@@ -81,3 +81,19 @@ def test_full_batch_properties(advanced):
         assert abs(full[p][13] - e["totalsnr"]) < 1e-9
     assert worst < 1e-6
     print(f"full size, {'advanced' if advanced else 'basic'}: max |dODG| vs oracle on 8 pairs {worst:.2e}")
+
+
+@pytest.mark.parametrize("advanced", [0, 1], ids=["basic", "advanced"])
+def test_one_minute_stream(advanced):
+    """a 60 s stereo pair (2812 frames / 15 000 filter-bank blocks; BS.1387 items run 10-30 s): the
+    recurrent state is carried through many chunks of the batch driver without drifting from the oracle"""
+    import torch
+    import gstpeaq_amd
+    n = 60 * 48000
+    ref, test = synth_np.pair(9001, CH, n)
+    got = gstpeaq_amd.batch_run(gpu.ctx(), advanced, torch.from_numpy(ref[None]).cuda(), torch.from_numpy(test[None]).cuda())[0]
+    e = orc.run_pair(advanced, ref, test)
+    assert got["frames"] == e["frames"] == 2812
+    nm = 5 if advanced else 11
+    np.testing.assert_allclose(got["movs"][:nm], e["movs"][:nm], rtol=1e-7, atol=1e-9)
+    assert abs(got["odg"] - e["odg"]) < 1e-6 and abs(got["totalsnr"] - e["totalsnr"]) < 1e-9
