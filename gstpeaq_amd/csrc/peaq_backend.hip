@@ -197,18 +197,18 @@ __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const
       const double a = bt.adapt_tc(bl.band(s));
       st[0][s] = a * st[0][s] + (1 - a) * e_ref[s];          // (42)/(43) in BS.1387
       st[1][s] = a * st[1][s] + (1 - a) * e_test[s];
-      num += sqrt(st[0][s] * st[1][s]);                      // (45)
+      num += sqrt_pos(st[0][s] * st[1][s]);                  // (45)
       den += st[1][s];
     }
   }
   num = wave_sum(num);
   den = wave_sum(den);
-  const double lev = num * num / (den * den);
+  const double lev = div_fast(num * num, den * den);
   double lc_ref[SLOTS], lc_test[SLOTS];
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     if (lev > 1) {                                           // (46)/(47)
-      lc_ref[s] = e_ref[s] / lev;
+      lc_ref[s] = div_fast(e_ref[s], lev);
       lc_test[s] = e_test[s];
     } else {
       lc_ref[s] = e_ref[s];
@@ -221,9 +221,9 @@ __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const
       st[3][s] = a * st[3][s] + lc_ref[s] * lc_ref[s];
       if (st[2][s] >= st[3][s]) {                            // (49)
         pr = 1.;
-        pt = st[3][s] / st[2][s];
+        pt = div_fast(st[3][s], st[2][s]);
       } else {
-        pr = st[2][s] / st[3][s];
+        pr = div_fast(st[2][s], st[3][s]);
         pt = 1.;
       }
     }
@@ -249,8 +249,9 @@ __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const
         rr += pa_lds[kPaPad + k + j];
         rt += pa_lds[kPaStride + kPaPad + k + j];
       }
-      rr /= (m1 + m2 + 1);
-      rt /= (m1 + m2 + 1);
+      const double cnt = (double)(m1 + m2 + 1);
+      rr = div_fast(rr, cnt);
+      rt = div_fast(rt, cnt);
       const double a = bt.adapt_tc(k);
       st[4][s] = a * st[4][s] + (1 - a) * rr;
       st[5][s] = a * st[5][s] + (1 - a) * rt;
@@ -274,7 +275,7 @@ __device__ __forceinline__ void modulation(const BandLane<NB, SLOTS>& bl, const 
       const double dl = bt.deriv_factor() * fabs(loud[s] - st[0][s]);
       st[2][s] = a * st[2][s] + (1 - a) * dl;
       st[1][s] = a * st[1][s] + (1. - a) * loud[s];
-      mod[s] = st[2][s] / (1. + st[1][s] / 0.3);
+      mod[s] = div_fast(st[2][s], 1. + div_fast(st[1][s], 0.3));
       st[0][s] = loud[s];
     }
   }
@@ -290,7 +291,7 @@ __device__ __forceinline__ double total_loudness(const BandLane<NB, SLOTS>& bl, 
     if (bl.valid(s)) {
       const int b = bl.band(s);
       const double thr = bt.threshold(b);
-      const double l = bt.loud_factor(b) * (pow_pos(1. - thr + thr * exc[s] / bt.exc_threshold(b), 0.23) - 1.);
+      const double l = bt.loud_factor(b) * (pow_pos(1. - thr + div_fast(thr * exc[s], bt.exc_threshold(b)), 0.23) - 1.);
       t += fmax(l, 0.);
     }
   }
@@ -310,9 +311,10 @@ __device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, 
       const double sref = thres_fac * mod_ref[s] + s0;
       const double stest = thres_fac * mod_test[s] + s0;
       const double ethres = bt.internal_noise(bl.band(s));
-      const double beta = exp_fast(-alpha * (e_test[s] - e_ref[s]) / e_ref[s]);
-      nl += pow_pos(ethres / stest, 0.23) *
-            (pow_pos(1. + fmax(stest * e_test[s] - sref * e_ref[s], 0.) / (ethres + sref * e_ref[s] * beta), 0.23) - 1.);
+      const double beta = exp_fast(div_fast(-alpha * (e_test[s] - e_ref[s]), e_ref[s]));
+      nl += pow_pos(div_fast(ethres, stest), 0.23) *
+            (pow_pos(1. + div_fast(fmax(stest * e_test[s] - sref * e_ref[s], 0.), ethres + sref * e_ref[s] * beta), 0.23) -
+             1.);
     }
   }
   nl = wave_sum(nl) * (24. / NB);
@@ -329,9 +331,9 @@ __device__ __forceinline__ void mod_difference(const BandLane<NB, SLOTS>& bl, co
   for (int s = 0; s < SLOTS; ++s) {
     if (bl.valid(s)) {
       const double diff = fabs(mr[s] - mt[s]);
-      a1 += diff / (1. + mr[s]);
-      a2 += (mt[s] >= mr[s] ? 1. : .1) * diff / (0.01 + mr[s]);
-      aw += loud_ref[s] / (loud_ref[s] + lev_wt * bt.noise_pow03(bl.band(s)));
+      a1 += div_fast(diff, 1. + mr[s]);
+      a2 += div_fast((mt[s] >= mr[s] ? 1. : .1) * diff, 0.01 + mr[s]);
+      aw += div_fast(loud_ref[s], loud_ref[s] + lev_wt * bt.noise_pow03(bl.band(s)));
     }
   }
   d1 = wave_sum(a1);
@@ -501,14 +503,14 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
           const double et_db = (10. * kInvLn10) * log_pos(et[s]);
           const double l = 0.3 * fmax(er_db, et_db) + 0.7 * et_db;
           const double l2 = l * l;
-          const double sd = l > 0. ? 5.95072 * pow_pos(6.39468 / l, 1.71332) + 9.01033e-11 * l2 * l2 +
+          const double sd = l > 0. ? 5.95072 * pow_pos(div_fast(6.39468, l), 1.71332) + 9.01033e-11 * l2 * l2 +
                                          5.05622e-6 * l2 * l - 0.00102438 * l * l + 0.0550197 * l - 0.198719
                                    : 1e30;
           const double e = er_db - et_db;
-          const double x = e / sd, x2 = x * x;
+          const double x = div_fast(e, sd), x2 = x * x;
           const double xb = er_db > et_db ? x2 * x2 : x2 * x2 * x2;   // (e/s)^b, b = 4 or 6
           pc = 1. - exp_fast(-kLn2 * xb);                             // 1 - 0.5^((e/s)^b)
-          qc = fabs(trunc(e)) / sd;
+          qc = div_fast(fabs(trunc(e)), sd);
         }
         sh.pc[chan][bl.band(s)] = pc;
         sh.qc[chan][bl.band(s)] = qc;
@@ -547,8 +549,8 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
 #pragma unroll
       for (int s = 0; s < SLOTS; ++s) {
         if (bl.valid(s)) {
-          const double m = er[s] / bt.mask_diff(bl.band(s));
-          const double r = nz[s] / m;
+          const double m = div_fast(er[s], bt.mask_diff(bl.band(s)));
+          const double r = div_fast(nz[s], m);
           nsum += r;
           if (r > nmax) nmax = r;
         }

@@ -407,8 +407,8 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
       // Kabal (23)-(24); fftearmodel.c:649-656.  a^y evaluated as exp(y ln a).
       const double ln_a = bt->ln_aUC[b] + bt->dz02 * log_pos(pp);
       const double a_uce = exp_fast(ln_a);
-      const double g_iu = (1. - exp_fast((double)(NB - b) * ln_a)) / (1. - a_uce);
-      const double en = pp / (bt->gIL[b] + g_iu - 1.);
+      const double g_iu = div_fast(1. - exp_fast((double)(NB - b) * ln_a), 1. - a_uce);
+      const double en = div_fast(pp, bt->gIL[b] + g_iu - 1.);
       ae[s] = exp_fast(0.4 * ln_a);
       ene[s] = pow_pos(en, 0.4);
     } else {
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     // (25): E = E2^(1/0.4) / normalisation, and E^0.3 for the modulation patterns (modpatt.c:235),
     // both from square roots: x^2.5 = x^2 sqrt(x), (x^2.5)^0.3 = x^0.75 = sqrt(x) sqrt(sqrt(x))
     const int bb = b < NB ? b : 0;
-    const double r1 = sqrt(e2), r2 = sqrt(r1);
+    const double r1 = sqrt_pos(e2), r2 = sqrt_pos(r1);
     unsm[s] = b < NB ? e2 * e2 * r1 * bt->inv_spread_norm[bb] : 0.;
     loud[s] = b < NB ? r1 * r2 * bt->inv_spread_norm_pow03[bb] : 0.;
   }
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     wave_lds_fence();
     for (int k = lane; k < kPwLen; k += 64) {
       const double r = pw_ref[k], t = pw_test[k];
-      pw_test[k] = r - 2 * sqrt(r * t) + t;
+      pw_test[k] = r - 2 * sqrt_pos(r * t) + t;
     }
     wave_lds_fence();
     if (lane < (NB + 1) / 2) {                        // balanced assignment as above, straight to the record

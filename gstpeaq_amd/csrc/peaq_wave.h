@@ -152,6 +152,32 @@ __device__ __forceinline__ double exp_fast(double x) {
   return __builtin_amdgcn_ldexp(p, (int)n);
 }
 
+// a / b for finite b of moderate magnitude (no scaling against overflow / underflow of the
+// reciprocal, no special cases): reciprocal with two Newton steps, quotient with one residual
+// correction; <= 1 ulp.  8 instructions instead of the 11 of the IEEE sequence.
+__device__ __forceinline__ double div_fast(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.), r, r);
+  r = fma(fma(-b, r, 1.), r, r);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
+
+// sqrt(x) for finite x >= 0 (0 -> 0), <= 1 ulp: reciprocal square root, two coupled Newton steps
+// on (sqrt, 1/(2 sqrt)), one residual correction.  14 instructions instead of 23.
+__device__ __forceinline__ double sqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  return x == 0. ? 0. : g;
+}
+
 constexpr double kInvLn10 = 0.43429448190325182765;   // log10 x = ln x / ln 10
 constexpr double kLn2 = 0.69314718055994530942;       // 2^x = e^(x ln 2)
 

@@ -28,7 +28,7 @@ __device__ double u01(uint64_t i, uint64_t salt) {   // splitmix64 -> [0, 1)
   z ^= z >> 31;
   return (double)(z >> 11) * (1. / 9007199254740992.);
 }
-__global__ void sweep(double* worst) {   // worst[0] log, [1] exp, [2] pow, [3] log near 1
+__global__ void sweep(double* worst) {   // worst[0] log, [1] exp, [2] pow, [3] log near 1, [4] div, [5] sqrt
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double w0, w1, w2, w3;
   {
@@ -45,8 +45,15 @@ __global__ void sweep(double* worst) {   // worst[0] log, [1] exp, [2] pow, [3] 
     const double x = exp2(u01(i, 5) * 120. - 60.), y = u01(i, 6) * 3.;   // 1e-18 .. 1e18, exponents 0 .. 3
     w2 = ulp_err(pow_pos(x, y), pow(x, y));
   }
-  double w[4] = {w0, w1, w2, w3};
-  for (int k = 0; k < 4; ++k) {
+  double w4, w5;
+  {
+    const double a = (u01(i, 7) - 0.5) * exp2(u01(i, 8) * 200. - 100.), b = exp2(u01(i, 9) * 400. - 200.) * (u01(i, 10) < 0.5 ? -1. : 1.);
+    w4 = ulp_err(div_fast(a, b), a / b);
+    const double x = exp2(u01(i, 11) * 1200. - 600.);
+    w5 = ulp_err(sqrt_pos(x), sqrt(x));
+  }
+  double w[6] = {w0, w1, w2, w3, w4, w5};
+  for (int k = 0; k < 6; ++k) {
     double v = w[k];
     for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(worst + k), __double_as_longlong(v));
@@ -62,9 +69,10 @@ __global__ void specials(double* out) {
   out[6] = exp_fast(800.);
   out[7] = exp_fast(0.);
   out[8] = log_pos(1.);
+  out[9] = sqrt_pos(0.);
 }
 int main() {
-  double *d_w, *d_s, w[4], s[9];
+  double *d_w, *d_s, w[6], s[10];
   if (hipMalloc(&d_w, sizeof w) != hipSuccess || hipMalloc(&d_s, sizeof s) != hipSuccess ||
       hipMemset(d_w, 0, sizeof w) != hipSuccess)
     return 2;
@@ -74,11 +82,11 @@ int main() {
       hipMemcpy(s, d_s, sizeof s, hipMemcpyDeviceToHost) != hipSuccess)
     return 2;
   printf("{\"n_per_function\": %d, \"log_pos_max_ulp\": %.3f, \"log_pos_near_1_max_ulp\": %.3f, \"exp_fast_max_ulp\": %.3f, "
-         "\"pow_pos_max_ulp\": %.3f, ", 1 << 24, w[0], w[3], w[1], w[2]);
+         "\"pow_pos_max_ulp\": %.3f, \"div_fast_max_ulp\": %.3f, \"sqrt_pos_max_ulp\": %.3f, ", 1 << 24, w[0], w[3], w[1], w[2], w[4], w[5]);
   printf("\"log_nonneg(0)\": \"%g\", \"log_nonneg(inf)\": \"%g\", \"log_nonneg(nan)\": \"%g\", \"log_nonneg(denorm_min)\": %.17g, "
          "\"exp_fast(-inf)\": %g, \"exp_fast(-800)\": %g, \"exp_fast(800)\": \"%g\", \"exp_fast(0)\": %.17g, \"log_pos(1)\": %g}\n",
          s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
   const bool ok = w[0] < 2.5 && w[3] < 2.5 && w[1] < 2.5 && std::isinf(s[0]) && s[0] < 0 && std::isinf(s[1]) && std::isnan(s[2]) &&
-                  s[4] == 0. && s[5] == 0. && std::isinf(s[6]) && s[7] == 1. && s[8] == 0.;
+                  s[4] == 0. && s[5] == 0. && std::isinf(s[6]) && s[7] == 1. && s[8] == 0. && s[9] == 0. && w[4] < 2.5 && w[5] < 2.5;
   return ok ? 0 : 1;
 }
