@@ -136,6 +136,19 @@ def main():
         value = frame_pairs_all * args.steps / elapsed
         fe_s = timing["frontend_ms"] * 1e-3
         achieved = frame_pairs_rank * ALGO_BYTES_PER_FRAME_PAIR / fe_s / 1e9 if fe_s > 0 else 0.0
+        # the bound that actually applies: FP64 vector issue.  VALU instructions per wave
+        # of the dominant kernel come from a rocprofv3 --pmc pass (profiles/r01_basic_1024_pmc_mix.json);
+        # one wave64 instruction occupies its SIMD for 4 cycles, an MI355X has 256 CUs x 4 SIMDs at 2.4 GHz
+        valu_frac = None
+        mix = ROOT / "profiles" / "r01_basic_1024_pmc_mix.json"
+        if mix.exists() and not args.advanced:
+            try:
+                k = next(v for n, v in json.loads(mix.read_text()).items() if "frontend_kernel<109>" in n)
+                per_wave = k["SQ_INSTS_VALU"]["avg"] / k["SQ_WAVES"]["avg"]
+                waves = frame_pairs_rank * args.channels * 2          # one wave per (frame, channel, signal)
+                valu_frac = waves * per_wave * 4 / (1024 * 2.4e9) / fe_s
+            except Exception:
+                valu_frac = None
         traffic = None
         prof = ROOT / "profiles" / "pmc_frontend.json"     # written from a rocprofv3 --pmc pass (see profiles/README.md)
         if prof.exists():
@@ -169,6 +182,7 @@ def main():
                          "algorithmic_bytes_per_launch": frame_pairs_rank * ALGO_BYTES_PER_FRAME_PAIR
                                                          / max(timing["frontend_launches"], 1),
                          "compute_frac_fp64_vector": value / world * FLOP_PER_FRAME_PAIR / (FP64_VECTOR_PEAK_TFLOPS * 1e12),
+                         "valu_issue_frac": valu_frac,
                          "backend_ms": timing["backend_ms"], "fb_ms": timing["fb_ms"],
                          "step_ms_events": timing["total_ms"]},
             "odg_mean": float(odg[~torch.isnan(odg)].mean().item()),
