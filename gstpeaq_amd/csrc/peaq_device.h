@@ -72,7 +72,6 @@ struct FbTables {               // fbearmodel.c:57-61,182-225
   double back_mask[6];
   double h_re[12000];           // sum(N/2+1) = 10954 coefficients
   double h_im[12000];
-  double h_ri[24000];           // the same, interleaved {re, im} per tap (one 16-byte load per tap)
   // A operands of the two GEMMs (see kMf* above): step s of tile r, lane = band_in_tile + 16 (d - d0 - 4 s);
   // the centre tap carries half its weight (its two "mirror" samples coincide)
   double mf_re[kMfTotalSteps * 64];

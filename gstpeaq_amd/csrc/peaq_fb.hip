@@ -9,15 +9,15 @@
 //                   reference's float running sum, bit for bit.  Output: the filtered
 //                   signal in FP64, one row per signal, staged through LDS so that the
 //                   stores are 64-byte runs.
-//  fb_bank_kernel   one WAVEFRONT per (pair, channel, signal), walking the chunk in
-//                   tiles of 60 sub-samples (= 10 blocks of 192 samples): lanes are
-//                   TIME points (every 32nd sample, fbearmodel.c:314), the filtered
-//                   signal window sits in LDS, the 40 complex FIR responses come in as
-//                   wave-uniform scalars.  Then, still with lanes = time: level
-//                   dependent spreading (slope filter as a wave scan, :327-354),
+//  fb_bank_kernel   one WORKGROUP of four waves per (pair, channel, signal), walking the
+//                   chunk in tiles of 60 sub-samples (= 10 blocks of 192 samples).  The
+//                   window of the filtered signal sits in LDS; the 40 complex FIR filters
+//                   (:399-435) run as two folded GEMMs on the matrix cores (fir_mfma
+//                   below).  Then with lanes = TIME points (every 32nd sample, :314):
+//                   level dependent spreading (slope filter as a wave scan, :327-354),
 //                   rectification (:357-360); the 11-tap backward-masking FIR at block
 //                   rate (:364-382), internal noise and forward masking (:385-394)
-//                   with lanes = bands.
+//                   with threads = bands.
 #include <hip/hip_runtime.h>
 
 #include "peaq_device.h"
@@ -25,16 +25,6 @@
 #include "peaq_wave.h"
 
 namespace peaq {
-
-// BS.1387 Table 8 (fbearmodel.c:57-61)
-__device__ constexpr int kLen[kFbBands] = {1456, 1438, 1406, 1362, 1308, 1244, 1176, 1104, 1030, 956, 884, 814, 748, 686,
-                                           626,  570,  520,  472,  430,  390,  354,  320,  290,  262, 238, 214, 194, 176,
-                                           158,  144,  130,  118,  106,  96,   86,   78,   70,   64,  58,  52};
-constexpr int coef_offset(int b) {
-  int o = 0;
-  for (int i = 0; i < b; ++i) o += kLen[i] / 2 + 1;
-  return o;
-}
 
 constexpr double kSlopeA = 0.993355506255034;      // fbearmodel.c:49
 constexpr double kLnDist = -0.08137117849224008;   // ln(0.921851456499719), DIST of fbearmodel.c:50

@@ -166,8 +166,6 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
       const double ph = 2 * kPi * fc[b] * (k - len / 2.0) / 48000.0;
       fb.h_re[off + k] = win * std::cos(ph);
       fb.h_im[off + k] = win * std::sin(ph);
-      fb.h_ri[2 * (off + k)] = fb.h_re[off + k];
-      fb.h_ri[2 * (off + k) + 1] = fb.h_im[off + k];
     }
     off += len / 2 + 1;
   }
