@@ -2,7 +2,8 @@
 // carries state from one frame to the next.  One workgroup per pair, one
 // wavefront per channel, frames processed in order; a lane owns two critical
 // bands (one for the 40-band filter bank) and keeps their recurrent state in
-// registers; lane i additionally owns MOV accumulator i of its channel.
+// registers; lane i additionally owns MOV accumulator i of its channel (its
+// twelve fields and the per-band constants live in LDS).
 //
 // Reference functions restated here (file:line under /root/reference/src):
 //   time smearing                    fftearmodel.c:496-504

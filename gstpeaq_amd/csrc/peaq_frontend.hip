@@ -16,12 +16,13 @@
 //   + internal noise                 :483-485
 //   level-dependent spreading        :637-676
 //   energy flag                      :508-514
-// plus the frame's stateless MOV ingredients, after one workgroup barrier:
-//   ref wave : error harmonic structure    movs.c:1346-1443
-//   test wave: noise-in-bands for NMR      movs.c:992-1000
-//              bandwidths                  movs.c:776-809
-//              totalsnr energies           gstpeaq.c:913-918
+// plus the frame's stateless MOV ingredients:
 //   ref wave : data-boundary detector      gstpeaq.c:1081-1099 (before the FFT)
+//   both     : bandwidths                  movs.c:776-809 (from the spectra in registers)
+//   both     : error harmonic structure    movs.c:1346-1443 (log ratio + autocorrelation
+//                                          shared, the rest on the ref wave)
+//   test wave: noise-in-bands for NMR      movs.c:992-1000
+//   ref wave : totalsnr energies           gstpeaq.c:913-918
 //
 // LDS per wave ("unit"), 10304 B: the 8.5 KiB FFT exchange buffer (real and
 // imaginary parts go through it one after the other) is reused for the weighted
