@@ -212,6 +212,18 @@ extern "C" int peaq_ctx_device(const peaq_ctx* c) { return c ? c->device : -1; }
 // ---------------------------------------------------------------------------
 static const size_t kRecordBudget = (size_t)1536 << 20;   // HBM for per-frame records of one chunk
 static const unsigned kFbBlocksPerChunk = 320;             // filter-bank blocks per launch (multiple of 10)
+static const size_t kFbRowBudget = (size_t)12 << 30;       // HBM for ONE buffer of high-passed rows
+
+// blocks per launch of the filter-bank path: 320 (32 tiles) unless the batch is so large that the
+// rows of that many blocks would not fit the budget; always a multiple of the tile (10 blocks)
+static unsigned fb_blocks_per_chunk(int n_pairs, int channels, uint32_t max_blocks) {
+  const size_t n_signals = (size_t)n_pairs * channels * 2;
+  const size_t per_signal = kFbRowBudget / std::max<size_t>(n_signals, 1) / sizeof(double);
+  size_t bc = per_signal > (size_t)kFbRing ? (per_signal - kFbRing) / kFbFrame : 0;
+  bc = std::min<size_t>(bc, kFbBlocksPerChunk) / 10 * 10;
+  bc = std::max<size_t>(bc, 10);
+  return static_cast<unsigned>(std::min<size_t>(bc, (max_blocks + 9) / 10 * 10));
+}
 
 static unsigned frames_per_chunk(int n_pairs, int channels, uint32_t max_frames) {
   const size_t per_frame = (size_t)n_pairs * channels * kRecDoubles * sizeof(double);
@@ -229,7 +241,7 @@ extern "C" size_t peaq_batch_workspace_bytes(int advanced, int channels, int n_p
   size_t b = 2 * (size_t)n_pairs * fc * channels * kRecDoubles * sizeof(double) + (size_t)n_pairs * sizeof(PairState) +
              (size_t)n_pairs * 4 * sizeof(uint32_t);
   if (advanced) {
-    const unsigned bc = kFbBlocksPerChunk;
+    const unsigned bc = fb_blocks_per_chunk(n_pairs, channels, count_frames(n_max, n_max, kFbFrame, kFbFrame));
     const size_t nbuf = count_frames(n_max, n_max, kFbFrame, kFbFrame) > bc ? 2 : 1;   // pipelined: double buffers
     b += nbuf * (size_t)n_pairs * bc * channels * kFbRecDoubles * sizeof(double);
     b += (size_t)n_pairs * channels * 2 *
@@ -244,7 +256,7 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
                                uint32_t max_blocks, hipStream_t stream) {
     // ---- filter-bank path: blocks of 192 samples (gstpeaq.c:648-652) ------------------
     const unsigned n_signals = (unsigned)n_pairs * channels * 2;
-    const unsigned bc = std::min<unsigned>(kFbBlocksPerChunk, (max_blocks + 9) / 10 * 10);
+    const unsigned bc = fb_blocks_per_chunk(n_pairs, channels, max_blocks);
     const size_t row_stride = (size_t)kFbRing + (size_t)bc * kFbFrame;
     const bool piped = max_blocks > bc;               // more than one chunk: 3-stage pipeline, double buffers
     HIP_TRY(c->hp_scratch.reserve((size_t)n_signals * row_stride * sizeof(double)));

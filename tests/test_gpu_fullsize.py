@@ -97,3 +97,28 @@ def test_one_minute_stream(advanced):
     nm = 5 if advanced else 11
     np.testing.assert_allclose(got["movs"][:nm], e["movs"][:nm], rtol=1e-7, atol=1e-9)
     assert abs(got["odg"] - e["odg"]) < 1e-6 and abs(got["totalsnr"] - e["totalsnr"]) < 1e-9
+
+
+def test_many_short_pairs_advanced_chunking():
+    """8192 stereo pairs of 2 s: so many signals that the filter-bank path has to shrink its chunk
+    (rows of high-passed samples are budgeted, peaq_capi.hip fb_blocks_per_chunk); results must not
+    depend on it -- the same seeds in a small batch (one chunk) give the same numbers"""
+    import torch
+    import gstpeaq_amd
+    ctx = gpu.ctx()
+    n = 2 * 48000
+    ref, test = gstpeaq_amd.synth_fill(ctx, 5000, 8192, CH, n)
+    big = gstpeaq_amd.batch_run(ctx, 1, ref, test, sync=False)
+    torch.cuda.synchronize()
+    big = big.cpu().numpy()
+    del ref, test
+    torch.cuda.empty_cache()
+    ref, test = gstpeaq_amd.synth_fill(ctx, 5000, 64, CH, n)
+    small = gstpeaq_amd.batch_run(ctx, 1, ref, test, sync=False)
+    torch.cuda.synchronize()
+    small = small.cpu().numpy()
+    assert np.all(big[:, 14] == 93) and np.all(big[:, 15] == 500)     # 92 whole frames + flush; 500 blocks
+    np.testing.assert_allclose(big[:64, :5], small[:, :5], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(big[:64, 11:14], small[:, 11:14], rtol=1e-9, atol=1e-9)
+    e = orc.run_pair(1, *synth_np.pair(5000 + 8191, CH, n))
+    np.testing.assert_allclose(big[8191, :5], e["movs"][:5], rtol=1e-7, atol=1e-9)
