@@ -188,6 +188,22 @@ def main():
             "odg_mean": float(odg[~torch.isnan(odg)].mean().item()),
             "odg_nan": int(torch.isnan(odg).sum().item()),
         }
+        if args.advanced and timing["fb_launches"]:
+            # configs[2]: the dominant kernel is the filter bank (fb_bank_kernel), a folded FIR bank on the
+            # matrix cores.  Algorithmic work as the reference counts it (fbearmodel.c:404-434): per tap
+            # pair two additions and two multiply-adds, 10 914 tap pairs per sub-sample, 6 sub-samples per
+            # 192-sample block; against the FP64 matrix peak (= FP64 vector peak, 78.6 TFLOP/s).
+            blocks = float(gathered[: args.pairs, 15].sum().item()) if world > 1 else float(results[:, 15].sum().item())
+            flops = blocks * args.channels * 2 * 6 * 10914 * 6
+            fb_s = timing["fb_ms"] * 1e-3
+            tf = flops / fb_s / 1e12
+            line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "kernel": "fb_bank_kernel",
+                                "launches": timing["fb_launches"],
+                                "avg_launch_ms": timing["fb_ms"] / timing["fb_launches"],
+                                "algorithmic_flop_per_launch": flops / timing["fb_launches"],
+                                "frontend_ms": timing["frontend_ms"], "backend_ms": timing["backend_ms"],
+                                "fb_ms": timing["fb_ms"], "step_ms_events": timing["total_ms"]}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(n_samples, args.channels, seed0, args.advanced)
         print(json.dumps(line))
