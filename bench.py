@@ -2,23 +2,35 @@
 """bench.py -- the headline metric of BASELINE.json on MI355X.
 
 A "step" is one pass of the PEAQ hot path (basic model) over one batch of
-synthetic (ref, test) pairs that already sit in HBM: BASELINE.json configs[1],
-"Basic PEAQ, 4096 synthetic 48 kHz stereo 10 s (ref,test) pairs batched on 1
-MI355X".  With --gpus N every rank (one process per GPU, launched by
-torch.distributed.run) processes its own 4096 pairs -- pairs are independent,
-there is no data-path collective; the only communication is a
-gather of the per-pair ODG scalars over RCCL after the timed region.
+synthetic (ref, test) pairs.
 
-Prints ONE JSON line (rank 0).  `value` = stereo 2048-sample frame-pairs per
+  --gpus 1 (default)  BASELINE.json configs[1]: 4096 synthetic 48 kHz stereo 10 s
+                      pairs, resident in HBM when the timed region starts.
+  --gpus N > 1        BASELINE.json configs[3]'s sharding: every GPU owns 32 768
+                      pairs (N = 8: 262 144 pairs), a contiguous block of pair
+                      indices (gstpeaq_amd.parallel.shard), consumed in WAVES of
+                      4096 pairs: 252 GB of input per GPU do not fit beside the
+                      workspace, so wave w is generated on the device into the
+                      same two buffers (not timed), then run
+                      (timed), and only its 128-byte result records are kept.
+                      One process per GPU (torch.distributed.run), no data-path
+                      collective; after the timed region the
+                      records are gathered with one RCCL all_gather.
+
+Prints ONE JSON line (rank 0): `value` = stereo 2048-sample frame-pairs per
 second over all GPUs; `roofline` prices the dominant kernel (the FFT ear-model
 front end) against HBM with the ALGORITHMIC 16 384 B per stereo frame-pair of
 SURVEY.md 8(d), from HIP events recorded around that kernel's launches on its
 stream; `cpu_baseline` times the reference element itself (oracle/_ref, built
-from the reference's sources) -- or the C oracle if that binary is absent -- on
-a bounded sample of the same seeded pairs on the host cores.
+from the reference's sources; the C oracle if that binary is absent) on one core
+and on all host cores; `odg_max_abs_delta` etc. compare the GPU results with the
+reference's on the pairs the single-core leg ran (the second half of
+BASELINE.json's metric); `advanced` carries configs[2] (advanced model, same
+pairs) with its own roofline (filter bank on the FP64 matrix cores).
 """
 import argparse
 import json
+import math
 import os
 import subprocess
 import sys
@@ -32,37 +44,127 @@ ALGO_BYTES_PER_FRAME_PAIR = 16384     # 1024 new samples x 2 ch x 2 signals x 4 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s
 FLOP_PER_FRAME_PAIR = 0.45e6          # SURVEY.md 8(d), reported alongside
 FP64_VECTOR_PEAK_TFLOPS = 78.6
+CONFIG4_PAIRS_PER_GPU = 32768         # BASELINE.json configs[3]: 262 144 pairs over 8 GPUs
+WAVE_PAIRS = 4096
 
 
-def cpu_baseline(n_samples, channels, seed0, advanced=False, budget_s=12.0):
-    """frame-pairs/s of the reference C path on ONE host core, bounded sample."""
-    cores = 1
+# ----------------------------------------------------------------------------------------------
+# CPU baseline (test infrastructure under oracle/, only ever the thing compared WITH)
+# ----------------------------------------------------------------------------------------------
+def _cpu_tool():
     ref_bin = ROOT / "oracle" / "_ref" / "ref_harness"
-    env = dict(os.environ)
-    # one 10 s stereo pair is ~0.055 s on the reference element, ~0.3 s on the oracle
-    pairs = max(2, int(budget_s / (0.75 if advanced else 0.055)))
-    try:
-        if ref_bin.exists():
-            out = subprocess.run([str(ref_bin), "time", str(int(advanced)), str(channels), str(seed0), str(pairs), str(n_samples)],
-                                 capture_output=True, text=True, timeout=240, env=env)
-            if out.returncode == 0:
-                d = json.loads(out.stdout.strip().splitlines()[-1])
-                return dict(value=d["frame_pairs_per_s"], unit="frame-pairs/s", cores=cores, kind="reference",
-                            sample=f"{d['pairs']} of the same seeded 10 s stereo pairs ({d['frame_pairs']} frame-pairs) "
-                                   f"through the reference `peaq` element (oracle/_ref), 1 thread, "
-                                   f"{d['seconds']:.1f} s; host has {os.cpu_count()} cores")
-    except Exception:
-        pass
-    pairs = max(2, int(budget_s / (1.5 if advanced else 0.3)))
+    if ref_bin.exists():
+        return str(ref_bin), "reference", "the reference `peaq` element (oracle/_ref)"
     cli = ROOT / "oracle" / "oracle_cli"
     if not cli.exists():
         subprocess.run(["make", "-C", str(ROOT / "oracle"), "oracle_cli"], capture_output=True)
-    out = subprocess.run([str(cli), "time", str(int(advanced)), str(channels), str(seed0), str(pairs), str(n_samples)],
-                         capture_output=True, text=True, timeout=180)
-    d = json.loads(out.stdout.strip().splitlines()[-1])
-    return dict(value=d["frame_pairs_per_s"], unit="frame-pairs/s", cores=cores, kind="port",
-                sample=f"{d['pairs']} of the same seeded 10 s stereo pairs ({d['frame_pairs']} frame-pairs) through "
-                       f"oracle/peaq_oracle.c, 1 thread, {d['seconds']:.1f} s; host has {os.cpu_count()} cores")
+    return str(cli), "port", "oracle/peaq_oracle.c"
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _run_json(cmd, timeout):
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    if out.returncode != 0:
+        raise RuntimeError(f"{cmd[0]} failed: {out.stderr[-300:]}")
+    return json.loads(out.stdout.strip().splitlines()[-1].replace('"nan"', "NaN").replace('"inf"', "Infinity")
+                      .replace('"-inf"', "-Infinity"))
+
+
+def cpu_single(n_samples, channels, seed0, advanced, budget_s):
+    """One core, bounded sample of the same seeded pairs; also returns the per-pair results."""
+    tool, kind, what = _cpu_tool()
+    per_pair = {("reference", False): 0.055, ("reference", True): 0.45, ("port", False): 0.3, ("port", True): 1.5}
+    pairs = max(2, int(budget_s / per_pair[(kind, bool(advanced))] * (n_samples / 480000.0) ** -1))
+    d = _run_json([tool, "time", str(int(advanced)), str(channels), str(seed0), str(pairs), str(n_samples)], 600)
+    base = dict(value=d["frame_pairs_per_s"], unit="frame-pairs/s", cores=1, kind=kind,
+                sample=f"{d['pairs']} of the same seeded pairs ({d['frame_pairs']} frame-pairs) through {what}, "
+                       f"1 thread, {d['seconds']:.1f} s")
+    return base, d
+
+
+def cpu_all_cores(n_samples, channels, seed0, advanced, pair_seconds, budget_s=6.0):
+    """One process per host core, each pushing its own seeded pairs through the element; the timed
+    regions start together (wall-clock rendezvous); value = all frame-pairs / (last end - first begin)."""
+    tool, kind, what = _cpu_tool()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    distinct = 2
+    repeats = max(1, int(math.ceil(budget_s / (distinct * pair_seconds))))
+    start = time.time() + 6.0 + cores * 0.01               # generation (~0.3 s per pair) + process start-up
+    procs = [subprocess.Popen([tool, "time", str(int(advanced)), str(channels), str(seed0 + 100000 + distinct * i),
+                               str(distinct), str(n_samples), str(repeats), f"{start:.3f}"],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(cores)]
+    res = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+            if p.returncode == 0:
+                res.append(json.loads(out.strip().splitlines()[-1].replace('"nan"', "NaN")))
+        except Exception:
+            p.kill()
+    if not res:
+        return None
+    frames = sum(r["frame_pairs"] for r in res)
+    wall = max(r["t_end"] for r in res) - min(r["t_begin"] for r in res)
+    late = sum(1 for r in res if r["t_begin"] > start + 0.25)
+    return dict(value=frames / wall, unit="frame-pairs/s", cores=len(res), nproc=os.cpu_count(), cpu_model=_cpu_model(),
+                kind=kind,
+                sample=f"{len(res)} processes (one per core) x {distinct} seeded pairs x {repeats} passes = {frames} "
+                       f"frame-pairs through {what}, timed regions started together, {wall:.1f} s wall"
+                       + (f" ({late} processes started late)" if late else ""))
+
+
+def result_deltas(gpu_rows, cpu, advanced):
+    """max |delta| of GPU vs CPU results over the pairs of the single-core leg (same seeds, same order)"""
+    import numpy as np
+    from gstpeaq_amd.capi import MOV_NAMES_ADVANCED, MOV_NAMES_BASIC
+    n = len(cpu["odg"])
+    g = np.asarray(gpu_rows[:n], dtype=np.float64)
+    odg_c, di_c = np.asarray(cpu["odg"], dtype=np.float64), np.asarray(cpu["di"], dtype=np.float64)
+    movs_c = np.asarray(cpu["movs"], dtype=np.float64).reshape(n, 11)
+    names = MOV_NAMES_ADVANCED if advanced else MOV_NAMES_BASIC
+    nan_mismatch = int((np.isnan(g[:, 12]) != np.isnan(odg_c)).sum())
+    ok = ~np.isnan(odg_c) & ~np.isnan(g[:, 12])
+    mov_rel = {}
+    for i, name in enumerate(names):
+        a, b = g[ok, i], movs_c[ok, i]
+        den = np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-12)
+        mov_rel[name] = float(np.max(np.abs(a - b) / den)) if a.size else None
+    return dict(odg_max_abs_delta=float(np.max(np.abs(g[ok, 12] - odg_c[ok]))) if ok.any() else None,
+                di_max_abs_delta=float(np.max(np.abs(g[ok, 11] - di_c[ok]))) if ok.any() else None,
+                mov_max_rel_delta=mov_rel, delta_pairs=int(n), delta_nan_mismatches=nan_mismatch)
+
+
+# ----------------------------------------------------------------------------------------------
+def profile_numbers():
+    """Counter-derived figures of the front end.  They are NOT measured in this run: they come from
+    separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh, tools/pmc_mix.sh),
+    committed under profiles/ together with the commit and kernel time they were taken at."""
+    out = dict(traffic=None, valu_per_wave=None, from_profile=None)
+    prof = ROOT / "profiles" / "pmc_frontend.json"
+    if prof.exists():
+        try:
+            d = json.loads(prof.read_text())
+            out["traffic"] = d.get("hbm_bytes_per_launch")
+            out["valu_per_wave"] = d.get("valu_insts_per_wave")
+            out["fp64_per_wave"] = d.get("valu_fp64_insts_per_wave")
+            out["from_profile"] = dict(file="profiles/pmc_frontend.json", commit=d.get("commit"),
+                                       kernel_avg_ms_in_profile=d.get("kernel_avg_ms"),
+                                       launches_in_profile=d.get("launches"))
+        except Exception:
+            pass
+    return out
 
 
 def main():
@@ -70,15 +172,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=4096, help="pairs per GPU (configs[1]: 4096)")
+    ap.add_argument("--pairs", type=int, default=None,
+                    help="pairs per GPU and step (default: 4096 = configs[1] at --gpus 1, 32768 = configs[3] beyond)")
+    ap.add_argument("--wave-pairs", type=int, default=WAVE_PAIRS, help="pairs resident at a time (waves mode)")
+    ap.add_argument("--waves", action="store_true", help="consume the pairs in waves also at --gpus 1")
     ap.add_argument("--seconds", type=float, default=10.0, help="length of each pair")
     ap.add_argument("--channels", type=int, default=2)
-    ap.add_argument("--advanced", action="store_true", help="configs[2] instead of configs[1]")
+    ap.add_argument("--advanced", action="store_true", help="configs[2] as the main metric instead of configs[1]")
+    ap.add_argument("--no-advanced", action="store_true", help="skip the `advanced` sub-object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import gstpeaq_amd
+    from gstpeaq_amd import parallel
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,118 +201,189 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
-    ctx = gstpeaq_amd.Context(local_rank)
+    waves_mode = args.waves or world > 1
+    pairs_per_gpu = args.pairs or (CONFIG4_PAIRS_PER_GPU if waves_mode else 4096)
+    wave_pairs = min(args.wave_pairs, pairs_per_gpu) if waves_mode else pairs_per_gpu
+    total_pairs = pairs_per_gpu * world
+    lo, hi = parallel.shard(total_pairs, rank, world)       # this rank's block of pair indices
     n_samples = int(round(args.seconds * 48000))
-    seed0 = 1 + rank * args.pairs                           # rank r owns pairs [r*P, (r+1)*P)
-    ref, test = gstpeaq_amd.synth_fill(ctx, seed0, args.pairs, args.channels, n_samples, device=dev)
-    results = torch.empty((args.pairs, 16), dtype=torch.float64, device=dev)
+    seed_base = 1                                            # pair i of the job carries seed seed_base + i
+
+    ctx = gstpeaq_amd.Context(local_rank)
+    ref, test = gstpeaq_amd.synth_fill(ctx, seed_base + lo, wave_pairs, args.channels, n_samples, device=dev)
+    results = torch.empty((hi - lo, 16), dtype=torch.float64, device=dev)
     torch.cuda.synchronize(dev)
 
-    def step():
-        gstpeaq_amd.batch_run(ctx, args.advanced, ref, test, results=results, sync=False)
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    timing = ctx.last_timing()                              # HIP events of the last step, on the launch stream
+    def run_steps(advanced, steps, warmup):
+        """-> (seconds inside the timed regions, wall seconds, HIP-event timing of the last pass)"""
+        if not waves_mode:
+            for _ in range(warmup):
+                gstpeaq_amd.batch_run(ctx, advanced, ref, test, results=results, sync=False)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                gstpeaq_amd.batch_run(ctx, advanced, ref, test, results=results, sync=False)
+            barrier()
+            el = time.perf_counter() - t0
+            return el, el, ctx.last_timing()
+        # waves: the resident buffers hold wave 0 on entry; a warm-up step runs that wave only
+        for _ in range(warmup):
+            gstpeaq_amd.batch_run(ctx, advanced, ref, test, results=results[:wave_pairs], sync=False)
+        barrier()
+        w0 = time.perf_counter()
+        timed = 0.0
+        for _ in range(steps):
+            timed += parallel.run_waves(ctx, advanced, seed_base + lo, hi - lo, wave_pairs, ref, test, results)
+        barrier()
+        wall = time.perf_counter() - w0
+        gstpeaq_amd.synth_fill(ctx, seed_base + lo, wave_pairs, args.channels, n_samples, out=(ref, test))
+        return timed, wall, ctx.last_timing()
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # the one collective of the path: gather the per-pair result records
-    from gstpeaq_amd import parallel
-    frame_pairs_rank = float(results[:, 14].sum().item())
-    gathered = parallel.gather_results(results, world, dist)
-    odg = gathered[:, 12]
-    frame_pairs_all = float(gathered[:, 14].sum().item())
+    def measure(advanced, steps, warmup):
+        timed, wall, timing = run_steps(advanced, steps, warmup)
+        timed, wall = reduce_max(timed), reduce_max(wall)
+        # the one collective of the path: gather the per-pair result records (SURVEY.md 8(e))
+        gathered = parallel.gather_results(results, world, dist)
+        frame_pairs_all = float(gathered[:, 14].sum().item())
+        frame_pairs_rank = float(results[:, 14].sum().item())
+        return dict(timed=timed, wall=wall, timing=timing, gathered=gathered, fp_all=frame_pairs_all,
+                    fp_rank=frame_pairs_rank, rows=results[: min(4096, hi - lo)].cpu().numpy().copy())
 
-    if rank == 0:
-        value = frame_pairs_all * args.steps / elapsed
+    def frontend_roofline(m, advanced):
+        timing = m["timing"]
+        # HIP events of the LAST batch call (one wave in waves mode) on the launch stream
+        last_pairs = wave_pairs if waves_mode else pairs_per_gpu
+        fp_last = m["fp_rank"] * last_pairs / (hi - lo)
+        if waves_mode and (hi - lo) % wave_pairs:
+            fp_last = m["fp_rank"] / (hi - lo) * ((hi - lo) % wave_pairs)
         fe_s = timing["frontend_ms"] * 1e-3
-        achieved = frame_pairs_rank * ALGO_BYTES_PER_FRAME_PAIR / fe_s / 1e9 if fe_s > 0 else 0.0
-        # the bound that actually applies: FP64 vector issue.  VALU instructions per wave
-        # of the dominant kernel come from a rocprofv3 --pmc pass (profiles/r01_basic_1024_pmc_mix.json);
-        # one wave64 instruction occupies its SIMD for 4 cycles, an MI355X has 256 CUs x 4 SIMDs at 2.4 GHz
+        achieved = fp_last * ALGO_BYTES_PER_FRAME_PAIR / fe_s / 1e9 if fe_s > 0 else 0.0
+        prof = profile_numbers()
         valu_frac = None
-        mix = ROOT / "profiles" / "r01_basic_1024_pmc_mix.json"
-        if mix.exists() and not args.advanced:
-            try:
-                k = next(v for n, v in json.loads(mix.read_text()).items() if "frontend_kernel<109>" in n)
-                per_wave = k["SQ_INSTS_VALU"]["avg"] / k["SQ_WAVES"]["avg"]
-                waves = frame_pairs_rank * args.channels * 2          # one wave per (frame, channel, signal)
-                valu_frac = waves * per_wave * 4 / (1024 * 2.4e9) / fe_s
-            except Exception:
-                valu_frac = None
-        traffic = None
-        prof = ROOT / "profiles" / "pmc_frontend.json"     # written from a rocprofv3 --pmc pass (see profiles/README.md)
-        if prof.exists():
-            try:
-                traffic = json.loads(prof.read_text()).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        if prof.get("valu_per_wave") and not advanced and fe_s > 0:
+            # FP64 VALU instructions occupy a SIMD for 4 cycles per wave, all others for 2
+            # (MI355X_MICROARCH.md: SIMD-32, FP64 at half the FP32 rate); 1024 SIMDs at 2.4 GHz
+            f64 = prof.get("fp64_per_wave") or 0.0
+            cyc = f64 * 4 + (prof["valu_per_wave"] - f64) * 2
+            valu_frac = fp_last * args.channels * 2 * cyc / (1024 * 2.4e9) / fe_s
+        launches = max(timing["frontend_launches"], 1)
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": prof["traffic"],
+                "kernel": "frontend_kernel<55>" if advanced else "frontend_kernel<109>", "launches": launches,
+                "avg_launch_ms": timing["frontend_ms"] / launches,
+                "algorithmic_bytes_per_launch": fp_last * ALGO_BYTES_PER_FRAME_PAIR / launches,
+                "compute_frac_fp64_vector": fp_last / fe_s * FLOP_PER_FRAME_PAIR / (FP64_VECTOR_PEAK_TFLOPS * 1e12)
+                if fe_s > 0 else None,
+                "valu_issue_frac": valu_frac, "from_profile": prof["from_profile"],
+                "from_profile_fields": ["traffic", "valu_issue_frac"],
+                "backend_ms": timing["backend_ms"], "fb_ms": timing["fb_ms"], "step_ms_events": timing["total_ms"]}
+
+    def filterbank_roofline(m):
+        # configs[2]: the dominant kernel is the filter bank (fb_bank_kernel), a folded FIR bank on the
+        # matrix cores.  Algorithmic work as the reference counts it (fbearmodel.c:404-434): per tap
+        # pair two additions and two multiply-adds, 10 914 tap pairs per sub-sample, 6 sub-samples per
+        # 192-sample block; against the FP64 matrix peak (= FP64 vector peak, 78.6 TFLOP/s).
+        timing = m["timing"]
+        last_pairs = wave_pairs if waves_mode else pairs_per_gpu
+        blocks = float(results[:last_pairs, 15].sum().item())
+        flops = blocks * args.channels * 2 * 6 * 10914 * 6
+        fb_s = timing["fb_ms"] * 1e-3
+        tf = flops / fb_s / 1e12 if fb_s > 0 else 0.0
+        return {"bound": "mfma", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "kernel": "fb_bank_kernel",
+                "launches": timing["fb_launches"], "avg_launch_ms": timing["fb_ms"] / max(timing["fb_launches"], 1),
+                "algorithmic_flop_per_launch": flops / max(timing["fb_launches"], 1),
+                "frontend_ms": timing["frontend_ms"], "backend_ms": timing["backend_ms"],
+                "fb_ms": timing["fb_ms"], "step_ms_events": timing["total_ms"]}
+
+    main_adv = bool(args.advanced)
+    m = measure(main_adv, args.steps, args.warmup)
+    odg = m["gathered"][:, 12]
+    line = None
+    if rank == 0:
+        value = m["fp_all"] * args.steps / m["timed"]
+        if waves_mode:
+            workload = (f"{'Advanced' if main_adv else 'Basic'} PEAQ, {total_pairs} synthetic 48 kHz "
+                        f"{'stereo' if args.channels == 2 else 'mono'} {args.seconds:g} s (ref,test) pairs sharded "
+                        f"over {world} GPU(s), {pairs_per_gpu} per GPU, consumed in waves of {wave_pairs} "
+                        f"(generated on the device between the timed regions) -- BASELINE.json configs[3]'s sharding")
+        else:
+            workload = (f"{'Advanced' if main_adv else 'Basic'} PEAQ, {pairs_per_gpu} synthetic 48 kHz "
+                        f"{'stereo' if args.channels == 2 else 'mono'} {args.seconds:g} s (ref,test) pairs per GPU, "
+                        f"inputs resident in HBM (BASELINE.json configs[{2 if main_adv else 1}])")
         line = {
-            "metric": "2048-sample stereo ref/test frame-pairs/sec (basic PEAQ, ear model -> MOVs -> ODG)"
-                      if not args.advanced else "FFT frame-pairs/sec (advanced PEAQ incl. filter-bank blocks)",
+            "metric": "2048-sample stereo ref/test frame-pairs/sec (basic PEAQ, ear model -> MOVs -> ODG); ODG delta vs CPU ref"
+                      if not main_adv else "FFT frame-pairs/sec (advanced PEAQ incl. filter-bank blocks); ODG delta vs CPU ref",
             "value": value,
             "unit": "frame-pairs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": m["timed"] / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{'Advanced' if args.advanced else 'Basic'} PEAQ, {args.pairs} synthetic 48 kHz "
-                                   f"{'stereo' if args.channels == 2 else 'mono'} {args.seconds:g} s (ref,test) pairs "
-                                   f"per GPU, inputs resident in HBM (BASELINE.json configs[{2 if args.advanced else 1}])",
-                       "pairs_per_gpu": args.pairs, "frame_pairs_per_pair": frame_pairs_rank / args.pairs,
+            "config": {"workload": workload, "pairs_per_gpu": pairs_per_gpu, "total_pairs": total_pairs,
+                       "frame_pairs_per_pair": m["fp_rank"] / (hi - lo),
+                       "waves_per_step": (hi - lo + wave_pairs - 1) // wave_pairs if waves_mode else 1,
                        "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "frontend_kernel<55>" if args.advanced else "frontend_kernel<109>", "launches": timing["frontend_launches"],
-                         "avg_launch_ms": timing["frontend_ms"] / max(timing["frontend_launches"], 1),
-                         "algorithmic_bytes_per_launch": frame_pairs_rank * ALGO_BYTES_PER_FRAME_PAIR
-                                                         / max(timing["frontend_launches"], 1),
-                         "compute_frac_fp64_vector": value / world * FLOP_PER_FRAME_PAIR / (FP64_VECTOR_PEAK_TFLOPS * 1e12),
-                         "valu_issue_frac": valu_frac,
-                         "backend_ms": timing["backend_ms"], "fb_ms": timing["fb_ms"],
-                         "step_ms_events": timing["total_ms"]},
+            "roofline": filterbank_roofline(m) if main_adv else frontend_roofline(m, False),
             "odg_mean": float(odg[~torch.isnan(odg)].mean().item()),
             "odg_nan": int(torch.isnan(odg).sum().item()),
         }
-        if args.advanced and timing["fb_launches"]:
-            # configs[2]: the dominant kernel is the filter bank (fb_bank_kernel), a folded FIR bank on the
-            # matrix cores.  Algorithmic work as the reference counts it (fbearmodel.c:404-434): per tap
-            # pair two additions and two multiply-adds, 10 914 tap pairs per sub-sample, 6 sub-samples per
-            # 192-sample block; against the FP64 matrix peak (= FP64 vector peak, 78.6 TFLOP/s).
-            blocks = float(gathered[: args.pairs, 15].sum().item()) if world > 1 else float(results[:, 15].sum().item())
-            flops = blocks * args.channels * 2 * 6 * 10914 * 6
-            fb_s = timing["fb_ms"] * 1e-3
-            tf = flops / fb_s / 1e12
-            line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "kernel": "fb_bank_kernel",
-                                "launches": timing["fb_launches"],
-                                "avg_launch_ms": timing["fb_ms"] / timing["fb_launches"],
-                                "algorithmic_flop_per_launch": flops / timing["fb_launches"],
-                                "frontend_ms": timing["frontend_ms"], "backend_ms": timing["backend_ms"],
-                                "fb_ms": timing["fb_ms"], "step_ms_events": timing["total_ms"]}
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(n_samples, args.channels, seed0, args.advanced)
+        if waves_mode:
+            line["wall_ms_per_step_incl_generation"] = m["wall"] / args.steps * 1e3
+    rows_main = m["rows"]
+
+    # ---- configs[2] next to configs[1] in the same line ---------------------------------------------
+    adv = None
+    if not main_adv and not args.no_advanced:
+        adv_steps = max(1, min(args.steps, 3))
+        ma = measure(True, adv_steps, 1)
+        if rank == 0:
+            adv = {"config": line["config"]["workload"].replace("Basic PEAQ", "Advanced PEAQ").replace("configs[1]", "configs[2]"),
+                   "metric": "FFT frame-pairs/sec (advanced PEAQ: 55-band FFT model + 40-band filter bank, 5 MOVs)",
+                   "value": ma["fp_all"] * adv_steps / ma["timed"], "unit": "frame-pairs/s", "steps": adv_steps,
+                   "warmup": 1, "ms_per_step": ma["timed"] / adv_steps * 1e3,
+                   "fb_blocks_per_frame_pair": float(ma["gathered"][:, 15].sum().item()) / max(ma["fp_all"], 1.0),
+                   "roofline": filterbank_roofline(ma),
+                   "odg_mean": float(ma["gathered"][:, 12][~torch.isnan(ma["gathered"][:, 12])].mean().item())}
+        rows_adv = ma["rows"]
+
+    # ---- CPU legs: rank 0, single GPU only (they would disturb the other ranks' timing otherwise) ------
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        try:
+            base, cpu = cpu_single(n_samples, args.channels, seed_base + lo, main_adv, 12.0)
+            line["cpu_baseline"] = base
+            line.update(result_deltas(rows_main, cpu, main_adv))
+            line["delta_vs"] = base["kind"]
+            pair_s = cpu["seconds"] / max(cpu["pairs"], 1)
+            allc = cpu_all_cores(n_samples, args.channels, seed_base + lo, main_adv, pair_s)
+            if allc:
+                line["cpu_baseline"]["all_cores"] = allc
+            if adv is not None:
+                abase, acpu = cpu_single(n_samples, args.channels, seed_base + lo, True, 5.0)
+                adv["cpu_baseline"] = abase
+                adv.update(result_deltas(rows_adv, acpu, True))
+        except Exception as e:                               # the bench line must survive a broken baseline leg
+            line["cpu_baseline_error"] = repr(e)[:300]
+    if rank == 0:
+        if adv is not None:
+            line["advanced"] = adv
         print(json.dumps(line))
     if dist:
         dist.barrier()

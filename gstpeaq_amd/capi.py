@@ -80,6 +80,8 @@ def load_library():
     L.peaq_session_flush.argtypes = [vp]
     L.peaq_session_results.argtypes = [vp, dp]
     L.peaq_session_reset.argtypes = [vp]
+    L.peaq_session_set_level.argtypes = [vp, C.c_double]
+    L.peaq_debug_backend.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp]
     L.peaq_batch_run.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, C.c_size_t,
                                  u32p, u32p, C.c_uint32, vp, vp]
     L.peaq_batch_workspace_bytes.restype = C.c_size_t
@@ -166,6 +168,9 @@ class Session:
 
     def flush(self):
         _check(self.L.peaq_session_flush(self.h))
+
+    def set_level(self, playback_level):
+        _check(self.L.peaq_session_set_level(self.h, float(playback_level)))
 
     def results(self):
         out = np.zeros(RESULT_DOUBLES)
@@ -278,11 +283,18 @@ def batch_run(ctx, advanced, ref, test, n_ref=None, n_test=None, playback_level=
     return [_result_dict(r, advanced) for r in rows]
 
 
-def synth_fill(ctx, seed0, n_pairs, channels, n_samples, device="cuda:0", stream=None):
-    """-> (ref, test) CUDA tensors [n_pairs, n_samples, channels] of include/peaq_synth.h pairs"""
+def synth_fill(ctx, seed0, n_pairs, channels, n_samples, device="cuda:0", stream=None, out=None):
+    """-> (ref, test) CUDA tensors [n_pairs, n_samples, channels] of include/peaq_synth.h pairs
+    seed0 .. seed0 + n_pairs - 1.  out=(ref, test): refill existing buffers (their first n_pairs
+    rows) instead of allocating -- how a GPU's share is consumed in waves."""
     import torch
-    ref = torch.empty((n_pairs, n_samples, channels), dtype=torch.float32, device=device)
-    test = torch.empty_like(ref)
+    if out is not None:
+        ref, test = out
+        assert ref.is_cuda and ref.is_contiguous() and test.is_contiguous() and ref.shape == test.shape
+        assert ref.shape[0] >= n_pairs and ref.shape[1] == n_samples and ref.shape[2] == channels
+    else:
+        ref = torch.empty((n_pairs, n_samples, channels), dtype=torch.float32, device=device)
+        test = torch.empty_like(ref)
     _check(ctx.L.peaq_synth_fill(ctx.h, int(seed0) & 0xFFFFFFFF, n_pairs, channels, n_samples, n_samples,
                                  C.c_void_p(ref.data_ptr()), C.c_void_p(test.data_ptr()), _stream_ptr(stream)))
     return ref, test
@@ -314,3 +326,26 @@ def debug_filterbank(ctx, ref, test, n_blocks, blocks_per_launch=320, playback_l
                                        C.c_void_p(test.data_ptr()), ref.shape[0], test.shape[0], n_blocks,
                                        blocks_per_launch, out.ctypes.data_as(C.POINTER(C.c_double))))
     return out
+
+
+BACKEND_DEBUG_DOUBLES = 904
+BACKEND_DEBUG_VECTORS = ["exc_ref", "exc_test", "adapted_ref", "adapted_test", "mod_ref", "mod_test",
+                         "avgloud_ref", "avgloud_test"]
+
+
+def debug_backend(ctx, records):
+    """Stage-level access to the stateful back end (basic version, fresh state).
+    records: np [frames, channels, 576] front-end records (from debug_frontend, or hand-built).
+    -> (dict name -> np [frames, channels, 109] for BACKEND_DEBUG_VECTORS plus 'loudness' [frames, channels, 2],
+        result dict after the last frame)"""
+    rec = np.ascontiguousarray(records, dtype=np.float64)
+    n_frames, channels, width = rec.shape
+    assert width == RECORD_DOUBLES
+    out = np.zeros((n_frames, channels, BACKEND_DEBUG_DOUBLES))
+    res = np.zeros(RESULT_DOUBLES)
+    dp = C.POINTER(C.c_double)
+    _check(ctx.L.peaq_debug_backend(ctx.h, channels, n_frames, rec.ctypes.data_as(dp), out.ctypes.data_as(dp),
+                                    res.ctypes.data_as(dp)))
+    d = {name: out[:, :, 112 * i: 112 * i + 109] for i, name in enumerate(BACKEND_DEBUG_VECTORS)}
+    d["loudness"] = out[:, :, 896:898]
+    return d, _result_dict(res, False)

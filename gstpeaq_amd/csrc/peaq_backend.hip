@@ -361,7 +361,9 @@ struct BackendShared {
 
 // 3 waves per SIMD requested: the back end runs BESIDE the front end of the next chunk (which
 // holds 3 x 168 VGPRs per SIMD); with the default budget (256) it could never be co-scheduled
-template <int NB, bool ADV>
+// DBG = true (basic version only, peaq_debug_backend): the per-frame patterns are also written to
+// a.debug for the stage-level parity tests; the arithmetic is the same instantiation otherwise.
+template <int NB, bool ADV, bool DBG = false>
 __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
   __shared__ BackendShared sh;
   __shared__ double sh_tab[T_COUNT * kBandStride];
@@ -490,10 +492,34 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
       level_adapt<NB, SLOTS>(bl, bt, er, et, la, &sh.pa[chan][0][0], ad_ref, ad_test);
       modulation<NB, SLOTS>(bl, bt, lr, mdr, mr);
       modulation<NB, SLOTS>(bl, bt, lt, mdt, mt);
+      if (DBG) {
+        double* __restrict__ d =
+            a.debug + ((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels + chan) * kDbgDoubles;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+          if (bl.valid(s)) {
+            const int b = bl.band(s);
+            d[kDbgExcRef + b] = er[s];
+            d[kDbgExcTest + b] = et[s];
+            d[kDbgAdaptRef + b] = ad_ref[s];
+            d[kDbgAdaptTest + b] = ad_test[s];
+            d[kDbgModRef + b] = mr[s];
+            d[kDbgModTest + b] = mt[s];
+            d[kDbgAvgLoudRef + b] = mdr[1][s];
+            d[kDbgAvgLoudTest + b] = mdt[1][s];
+          }
+        }
+      }
       if (loud_reached == UINT_MAX) {                // wave-uniform
         const double n_ref = total_loudness<NB, SLOTS>(bl, bt, er);
         const double n_test = total_loudness<NB, SLOTS>(bl, bt, et);
         if (lane == 0) sh.gate[chan] = (n_ref > 0.1 && n_test > 0.1);
+        if (DBG && lane == 0) {
+          double* __restrict__ d =
+              a.debug + ((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels + chan) * kDbgDoubles;
+          d[kDbgLoudnessRef] = n_ref;
+          d[kDbgLoudnessTest] = n_test;
+        }
       }
       // ---- detection probability, per channel part (movs.c:1239-1262) -----------------
 #pragma unroll
@@ -636,7 +662,9 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
 hipError_t launch_backend(const BackendArgs& a, unsigned n_pairs, hipStream_t stream) {
   if (n_pairs == 0) return hipSuccess;
   const dim3 block(64 * a.channels);
-  if (!a.advanced)
+  if (!a.advanced && a.debug)
+    hipLaunchKernelGGL((backend_kernel<109, false, true>), dim3(n_pairs), block, 0, stream, a);
+  else if (!a.advanced)
     hipLaunchKernelGGL((backend_kernel<109, false>), dim3(n_pairs), block, 0, stream, a);
   else
     hipLaunchKernelGGL((backend_kernel<55, true>), dim3(n_pairs), block, 0, stream, a);

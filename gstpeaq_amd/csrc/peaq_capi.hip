@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -30,6 +31,7 @@ using namespace peaq;
 
 static_assert(sizeof(ResultRecord) == sizeof(peaq_result), "result layouts must match");
 static_assert(kRecDoubles == PEAQ_DEBUG_RECORD_DOUBLES, "record layouts must match");
+static_assert(kDbgDoubles == PEAQ_DEBUG_BACKEND_DOUBLES, "debug layouts must match");
 
 // ---------------------------------------------------------------------------
 // errors
@@ -92,6 +94,11 @@ struct DevBuf {
   T* as() const { return static_cast<T*>(p); }
 };
 
+// a DevBuf that frees itself on every way out of a function (the debug entry points)
+struct TmpBuf : DevBuf {
+  ~TmpBuf() { release(); }
+};
+
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
@@ -141,6 +148,7 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
   peaq_ctx* c = new (std::nothrow) peaq_ctx;
   if (!c) return fail(PEAQ_ERR_NOMEM, "out of host memory");
   c->device = device;
+  const int rc = [&]() -> int {
   {
     std::vector<CommonTables> h(1);
     build_common_tables(h[0]);
@@ -173,6 +181,13 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->aux3, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->aux4, hipStreamNonBlocking));
+    return PEAQ_OK;
+  }();
+  if (rc != PEAQ_OK) {           // nothing allocated so far is leaked (destroy copes with a half-built context)
+    const std::string msg = g_err;
+    peaq_ctx_destroy(c);
+    return fail(rc, msg);
+  }
   *out = c;
   return PEAQ_OK;
 }
@@ -347,6 +362,10 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
   return PEAQ_OK;
 }
 
+static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double level_db, int n_pairs, const float* d_ref,
+                            const float* d_test, size_t pair_stride, const uint32_t* n_ref, const uint32_t* n_test,
+                            uint32_t n_uniform, peaq_result* d_results, hipStream_t stream);
+
 extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double level_db, int n_pairs,
                               const float* d_ref, const float* d_test, size_t pair_stride, const uint32_t* n_ref,
                               const uint32_t* n_test, uint32_t n_uniform, peaq_result* d_results, void* stream_) {
@@ -366,6 +385,22 @@ extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double le
   }
   c->spans.clear();
   c->events_used = 0;
+  const int rc = batch_run_locked(c, advanced, channels, level_db, n_pairs, d_ref, d_test, pair_stride, n_ref, n_test,
+                                  n_uniform, d_results, stream);
+  if (rc != PEAQ_OK) {
+    // part of the pipeline may already run on the context's own streams: nothing may touch the
+    // workspace (or free it) before that work has drained
+    const std::string msg = g_err;
+    (void)hipDeviceSynchronize();
+    c->batch_pending = false;
+    return fail(rc, msg);
+  }
+  return PEAQ_OK;
+}
+
+static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double level_db, int n_pairs, const float* d_ref,
+                            const float* d_test, size_t pair_stride, const uint32_t* n_ref, const uint32_t* n_test,
+                            uint32_t n_uniform, peaq_result* d_results, hipStream_t stream) {
 
   // ---- frame counts -------------------------------------------------------------------
   uint32_t max_frames = 0, max_blocks = 0;
@@ -539,12 +574,13 @@ extern "C" int peaq_debug_frontend(peaq_ctx* c, int bands, int channels, double 
   if (n_frames == 0) return PEAQ_OK;
   HIP_TRY(hipSetDevice(c->device));
   const size_t bytes = (size_t)n_frames * channels * kRecDoubles * sizeof(double);
-  double* d_rec = nullptr;
-  HIP_TRY(hipMalloc(&d_rec, bytes));
+  TmpBuf rec_buf, n_buf;
+  HIP_TRY(rec_buf.reserve(bytes));
+  double* d_rec = rec_buf.as<double>();
   HIP_TRY(hipMemset(d_rec, 0, bytes));
   uint32_t h_n[2] = {n_ref, n_test};
-  uint32_t* d_n = nullptr;
-  HIP_TRY(hipMalloc(&d_n, sizeof h_n));
+  HIP_TRY(n_buf.reserve(sizeof h_n));
+  uint32_t* d_n = n_buf.as<uint32_t>();
   HIP_TRY(hipMemcpy(d_n, h_n, sizeof h_n, hipMemcpyHostToDevice));
   FrontendArgs fa{};
   fa.ref = d_ref;
@@ -564,8 +600,6 @@ extern "C" int peaq_debug_frontend(peaq_ctx* c, int bands, int channels, double 
   hipError_t e = launch_frontend(bands, fa, 1, nullptr);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipMemcpy(host_out, d_rec, bytes, hipMemcpyDeviceToHost);
-  (void)hipFree(d_rec);
-  (void)hipFree(d_n);
   if (e != hipSuccess) return fail(PEAQ_ERR_DEVICE, std::string("peaq_debug_frontend: ") + hipGetErrorString(e));
   return PEAQ_OK;
 }
@@ -582,7 +616,7 @@ extern "C" int peaq_debug_filterbank(peaq_ctx* c, int channels, double level_db,
   HIP_TRY(hipSetDevice(c->device));
   const unsigned n_signals = 2 * channels;
   const size_t row_stride = (size_t)kFbRing + (size_t)blocks_per_launch * kFbFrame;
-  DevBuf rows, recs, st;
+  TmpBuf rows, recs, st;
   HIP_TRY(rows.reserve(n_signals * row_stride * sizeof(double)));
   HIP_TRY(recs.reserve((size_t)blocks_per_launch * channels * kFbRecDoubles * sizeof(double)));
   HIP_TRY(st.reserve(n_signals * sizeof(FbSignalState)));
@@ -618,10 +652,41 @@ extern "C" int peaq_debug_filterbank(peaq_ctx* c, int channels, double level_db,
                     (size_t)nb * channels * kFbRecDoubles * sizeof(double), hipMemcpyDeviceToHost);
     prev = nb;
   }
-  rows.release();
-  recs.release();
-  st.release();
   if (e != hipSuccess) return fail(PEAQ_ERR_DEVICE, std::string("peaq_debug_filterbank: ") + hipGetErrorString(e));
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_debug_backend(peaq_ctx* c, int channels, int n_frames, const double* host_records,
+                                  double* host_out, peaq_result* result) {
+  if (!c || !host_records || !host_out) return fail(PEAQ_ERR_ARG, "peaq_debug_backend: NULL argument");
+  if (channels != 1 && channels != 2) return fail(PEAQ_ERR_ARG, "peaq_debug_backend: channels must be 1 or 2");
+  if (n_frames < 1) return fail(PEAQ_ERR_ARG, "peaq_debug_backend: n_frames < 1");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t rec_bytes = (size_t)n_frames * channels * kRecDoubles * sizeof(double);
+  const size_t dbg_bytes = (size_t)n_frames * channels * kDbgDoubles * sizeof(double);
+  TmpBuf recs, dbg, st, res;
+  HIP_TRY(recs.reserve(rec_bytes));
+  HIP_TRY(dbg.reserve(dbg_bytes));
+  HIP_TRY(st.reserve(sizeof(PairState)));
+  HIP_TRY(res.reserve(sizeof(ResultRecord)));
+  HIP_TRY(hipMemcpy(recs.p, host_records, rec_bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(dbg.p, 0, dbg_bytes));
+  HIP_TRY(launch_state_init(st.as<PairState>(), 0, 1, nullptr));
+  BackendArgs ba{};
+  ba.records = recs.as<double>();
+  ba.frame0 = 0;
+  ba.frames_per_launch = n_frames;
+  ba.n_frames_uniform = n_frames;
+  ba.channels = channels;
+  ba.advanced = 0;
+  ba.bands = c->d_bands109;
+  ba.state = st.as<PairState>();
+  ba.debug = dbg.as<double>();
+  HIP_TRY(launch_backend(ba, 1, nullptr));
+  HIP_TRY(launch_finalize(st.as<PairState>(), 0, channels, 1, res.as<ResultRecord>(), nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host_out, dbg.p, dbg_bytes, hipMemcpyDeviceToHost));
+  if (result) HIP_TRY(hipMemcpy(result, res.p, sizeof(peaq_result), hipMemcpyDeviceToHost));
   return PEAQ_OK;
 }
 
@@ -633,11 +698,31 @@ namespace {
 constexpr unsigned kSessionMaxFrames = 64;   // FFT frames per launch of a session
 constexpr unsigned kSessionMaxBlocks = 120;  // filter-bank blocks per launch of a session
 
-// host-side stand-in for a GstAdapter: the not yet consumed tail of one pad's stream
+// host-side stand-in for a GstAdapter: the not yet consumed tail of one pad's stream.
+// Consumed samples are skipped with a read offset and the storage is compacted only once more
+// than half of it is dead, so a pad that runs far ahead of the other one (a whole file pushed on
+// `ref` before `test` starts) costs O(n) in total, like gst_adapter_flush, not O(n^2).
 struct PadFifo {
-  std::vector<float> buf;   // interleaved
-  uint64_t base = 0;        // stream sample index (per channel) of buf[0]
+  std::vector<float> buf;   // interleaved; live data starts at buf[head]
+  size_t head = 0;
+  uint64_t base = 0;        // stream sample index (per channel) of buf[head]
   uint64_t total = 0;       // samples (per channel) pushed so far
+  const float* at(uint64_t pos, int channels) const { return buf.data() + head + (size_t)(pos - base) * channels; }
+  size_t live_floats() const { return buf.size() - head; }
+  void append(const float* data, size_t n_floats) { buf.insert(buf.end(), data, data + n_floats); }
+  void drop_until(uint64_t keep_from, int channels) {
+    if (keep_from <= base) return;
+    const size_t drop = std::min((size_t)(keep_from - base) * channels, live_floats());
+    head += drop;
+    base = keep_from;
+    if (head == buf.size()) {
+      buf.clear();
+      head = 0;
+    } else if (head >= 65536 && head > buf.size() / 2) {
+      buf.erase(buf.begin(), buf.begin() + head);
+      head = 0;
+    }
+  }
 };
 
 }  // namespace
@@ -737,10 +822,9 @@ static int session_stage(peaq_session* s, const uint64_t pos[2], const uint64_t 
   }
   for (int p = 0; p < 2; ++p) {
     const PadFifo& f = s->pad[p];
-    const size_t off = (size_t)(pos[p] - f.base) * s->channels;
     const size_t cnt = (size_t)n_valid[p] * s->channels;
     if (cnt) {
-      std::memcpy(s->h_stage[p], f.buf.data() + off, cnt * sizeof(float));
+      std::memcpy(s->h_stage[p], f.at(pos[p], s->channels), cnt * sizeof(float));
       HIP_TRY(hipMemcpyAsync(s->d_sig[p].p, s->h_stage[p], cnt * sizeof(float), hipMemcpyHostToDevice, s->stream));
     }
   }
@@ -832,11 +916,7 @@ static void session_trim(peaq_session* s) {
   for (int p = 0; p < 2; ++p) {
     PadFifo& f = s->pad[p];
     const uint64_t keep_from = s->advanced ? std::min(s->fft_pos[p], s->fb_pos[p]) : s->fft_pos[p];
-    if (keep_from > f.base) {
-      const size_t drop = (size_t)(keep_from - f.base) * s->channels;
-      f.buf.erase(f.buf.begin(), f.buf.begin() + std::min(drop, f.buf.size()));
-      f.base = keep_from;
-    }
+    f.drop_until(keep_from, s->channels);
   }
 }
 
@@ -879,7 +959,7 @@ extern "C" int peaq_session_push(peaq_session* s, int pad, const float* data, si
   HIP_TRY(hipSetDevice(s->ctx->device));
   PadFifo& f = s->pad[pad];
   try {
-    f.buf.insert(f.buf.end(), data, data + n * s->channels);
+    f.append(data, n * s->channels);
   } catch (const std::bad_alloc&) {
     return fail(PEAQ_ERR_NOMEM, "out of host memory");
   }
@@ -925,6 +1005,15 @@ extern "C" int peaq_session_results(peaq_session* s, peaq_result* out) {
   return PEAQ_OK;
 }
 
+extern "C" int peaq_session_set_level(peaq_session* s, double level_db) {
+  if (!s) return fail(PEAQ_ERR_ARG, "peaq_session_set_level: session is NULL");
+  if (!(level_db >= 0. && level_db <= 130.))
+    return fail(PEAQ_ERR_ARG, "peaq_session_set_level: playback level outside 0..130 dB (gstpeaq.c:275-281)");
+  std::lock_guard<std::mutex> lock(s->mu);
+  s->level_db = level_db;            // the level factors are per-launch kernel arguments
+  return PEAQ_OK;
+}
+
 extern "C" int peaq_session_reset(peaq_session* s) {
   if (!s) return fail(PEAQ_ERR_ARG, "peaq_session_reset: session is NULL");
   std::lock_guard<std::mutex> lock(s->mu);
@@ -966,6 +1055,11 @@ constexpr unsigned kBrokerMaxBlocks = 48;    // filter-bank blocks one session c
 constexpr size_t kBrokerStageSamples = (size_t)(kBrokerMaxFrames - 1) * kHop + kFrame;
 constexpr size_t kBrokerFbStageSamples = (size_t)kBrokerMaxBlocks * kFbFrame;
 constexpr size_t kBrokerRowStride = (size_t)kFbRing + kBrokerFbStageSamples;
+// back-pressure: a push returns only once its session has no more than this many samples that are
+// READY to be framed (present on both pads) and not yet launched -- four ticks' worth.  Samples one
+// pad holds ahead of the other are never counted: like the reference's adapters they may pile up
+// without bound while the other pad is silent (gstpeaq.c:626-636).
+constexpr uint64_t kBrokerBacklog = (uint64_t)4 * kBrokerMaxFrames * kHop;
 
 struct BrokerSlot {
   std::mutex mu;
@@ -1018,7 +1112,11 @@ struct peaq_broker {
   std::thread worker;
   std::atomic<bool> running{false};
   unsigned period_us = 0;
+  std::atomic<bool> failed{false};  // a tick hit a device error: every later call reports it
+  std::mutex err_mu;                // guards worker_error
   std::string worker_error;
+  std::mutex cv_mu;                 // pushers blocked by the back-pressure wait here for the next tick
+  std::condition_variable tick_cv;
   uint64_t n_ticks = 0, n_launches = 0, n_frames = 0;
   uint32_t max_active = 0;
 };
@@ -1030,8 +1128,7 @@ static void broker_stage_copy(const peaq_broker* b, const BrokerSlot& sl, const 
   for (int p = 0; p < 2; ++p) {
     const PadFifo& f = sl.pad[p];
     if (nv[p])
-      std::memcpy(st.h[p] + idx * stride, f.buf.data() + (size_t)(pos[p] - f.base) * b->channels,
-                  (size_t)nv[p] * b->channels * sizeof(float));
+      std::memcpy(st.h[p] + idx * stride, f.at(pos[p], b->channels), (size_t)nv[p] * b->channels * sizeof(float));
   }
 }
 
@@ -1126,11 +1223,7 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
     for (int p = 0; p < 2; ++p) {
       PadFifo& f = sl.pad[p];
       const uint64_t keep_from = b->advanced ? std::min(sl.fft_pos[p], sl.fb_pos[p]) : sl.fft_pos[p];
-      if (keep_from > f.base) {
-        const size_t drop = (size_t)(keep_from - f.base) * b->channels;
-        f.buf.erase(f.buf.begin(), f.buf.begin() + std::min(drop, f.buf.size()));
-        f.base = keep_from;
-      }
+      f.drop_until(keep_from, b->channels);
     }
   }
   ++b->n_ticks;
@@ -1210,6 +1303,26 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
   return PEAQ_OK;
 }
 
+// one tick under tick_mu; a failure is remembered and stops the broker for good
+static int broker_tick_checked(peaq_broker* b, unsigned* n_active) {
+  if (b->failed.load()) {
+    std::lock_guard<std::mutex> e(b->err_mu);
+    return fail(PEAQ_ERR_DEVICE, "broker stopped after a device error: " + b->worker_error);
+  }
+  const int rc = broker_tick_locked(b, n_active);
+  if (rc != PEAQ_OK) {
+    std::lock_guard<std::mutex> e(b->err_mu);
+    b->worker_error = g_err;
+    b->failed.store(true);
+  }
+  return rc;
+}
+
+static int broker_failed(peaq_broker* b, const char* who) {
+  std::lock_guard<std::mutex> e(b->err_mu);
+  return fail(PEAQ_ERR_DEVICE, std::string(who) + ": broker stopped after a device error: " + b->worker_error);
+}
+
 extern "C" int peaq_broker_create(peaq_ctx* c, int advanced, int channels, double level_db, int max_sessions,
                                   peaq_broker** out) {
   if (!c || !out) return fail(PEAQ_ERR_ARG, "peaq_broker_create: NULL argument");
@@ -1264,6 +1377,7 @@ extern "C" int peaq_broker_create(peaq_ctx* c, int advanced, int channels, doubl
 extern "C" int peaq_broker_stop(peaq_broker* b) {
   if (!b) return fail(PEAQ_ERR_ARG, "peaq_broker_stop: broker is NULL");
   if (b->running.exchange(false) && b->worker.joinable()) b->worker.join();
+  b->tick_cv.notify_all();          // blocked pushers go on ticking inline
   return PEAQ_OK;
 }
 
@@ -1336,23 +1450,46 @@ extern "C" int peaq_broker_push(peaq_broker* b, int session_id, int pad, const f
   BrokerSlot* sl = broker_slot(b, session_id);
   if (!sl) return fail(PEAQ_ERR_ARG, "peaq_broker_push: bad broker or session id");
   if (pad != 0 && pad != 1) return fail(PEAQ_ERR_ARG, "peaq_broker_push: pad must be 0 (ref) or 1 (test)");
+  if (b->failed.load()) return broker_failed(b, "peaq_broker_push");
   if (n == 0) return PEAQ_OK;
   if (!data) return fail(PEAQ_ERR_ARG, "peaq_broker_push: data is NULL");
-  std::lock_guard<std::mutex> lock(sl->mu);
-  if (!sl->open) return fail(PEAQ_ERR_STATE, "peaq_broker_push: session is not open");
-  PadFifo& f = sl->pad[pad];
-  try {
-    f.buf.insert(f.buf.end(), data, data + n * b->channels);
-  } catch (const std::bad_alloc&) {
-    return fail(PEAQ_ERR_NOMEM, "out of host memory");
+  auto backlog = [&]() {
+    std::lock_guard<std::mutex> lock(sl->mu);
+    uint64_t r = std::min(sl->pad[0].total - sl->fft_pos[0], sl->pad[1].total - sl->fft_pos[1]);
+    if (b->advanced) r = std::max(r, std::min(sl->pad[0].total - sl->fb_pos[0], sl->pad[1].total - sl->fb_pos[1]));
+    return r;
+  };
+  {
+    std::lock_guard<std::mutex> lock(sl->mu);
+    if (!sl->open) return fail(PEAQ_ERR_STATE, "peaq_broker_push: session is not open");
+    PadFifo& f = sl->pad[pad];
+    try {
+      f.append(data, n * b->channels);
+    } catch (const std::bad_alloc&) {
+      return fail(PEAQ_ERR_NOMEM, "out of host memory");
+    }
+    f.total += n;
   }
-  f.total += n;
+  // back-pressure (the reference processes inside pad_chain, so its caller can never run ahead):
+  // wait for the tick thread, or tick right here when there is none
+  while (backlog() > kBrokerBacklog) {
+    if (b->failed.load()) return broker_failed(b, "peaq_broker_push");
+    if (b->running.load()) {
+      std::unique_lock<std::mutex> w(b->cv_mu);
+      b->tick_cv.wait_for(w, std::chrono::milliseconds(20));
+    } else {
+      std::lock_guard<std::mutex> tick(b->tick_mu);
+      const int rc = broker_tick_checked(b, nullptr);
+      if (rc != PEAQ_OK) return rc;
+    }
+  }
   return PEAQ_OK;
 }
 
 extern "C" int peaq_broker_flush(peaq_broker* b, int session_id) {
   BrokerSlot* sl = broker_slot(b, session_id);
   if (!sl) return fail(PEAQ_ERR_ARG, "peaq_broker_flush: bad broker or session id");
+  if (b->failed.load()) return broker_failed(b, "peaq_broker_flush");
   std::lock_guard<std::mutex> lock(sl->mu);
   if (!sl->open) return fail(PEAQ_ERR_STATE, "peaq_broker_flush: session is not open");
   sl->flush_requested = true;
@@ -1363,7 +1500,7 @@ extern "C" int peaq_broker_flush(peaq_broker* b, int session_id) {
 extern "C" int peaq_broker_tick(peaq_broker* b, unsigned* n_active) {
   if (!b) return fail(PEAQ_ERR_ARG, "peaq_broker_tick: broker is NULL");
   std::lock_guard<std::mutex> tick(b->tick_mu);
-  return broker_tick_locked(b, n_active);
+  return broker_tick_checked(b, n_active);
 }
 
 // true while the session has whole frames / blocks (or a requested flush) not yet launched
@@ -1386,8 +1523,9 @@ extern "C" int peaq_broker_results(peaq_broker* b, int session_id, peaq_result* 
     std::lock_guard<std::mutex> lock(sl->mu);
     if (!sl->open) return fail(PEAQ_ERR_STATE, "peaq_broker_results: session is not open");
   }
+  if (b->failed.load()) return broker_failed(b, "peaq_broker_results");
   while (broker_slot_busy(b, sl)) {
-    const int rc = broker_tick_locked(b, nullptr);
+    const int rc = broker_tick_checked(b, nullptr);
     if (rc != PEAQ_OK) return rc;
   }
   HIP_TRY(hipSetDevice(b->ctx->device));
@@ -1409,9 +1547,9 @@ extern "C" int peaq_broker_start(peaq_broker* b, unsigned period_us) {
       int rc;
       {
         std::lock_guard<std::mutex> tick(b->tick_mu);
-        rc = broker_tick_locked(b, nullptr);
-        if (rc != PEAQ_OK) b->worker_error = g_err;
+        rc = broker_tick_checked(b, nullptr);
       }
+      b->tick_cv.notify_all();
       if (rc != PEAQ_OK) break;
       next += std::chrono::microseconds(b->period_us);
       const auto now = std::chrono::steady_clock::now();
@@ -1429,6 +1567,6 @@ extern "C" int peaq_broker_stats(peaq_broker* b, peaq_broker_stats_t* out) {
   out->launches = b->n_launches;
   out->frames = b->n_frames;
   out->max_active = b->max_active;
-  out->worker_failed = b->worker_error.empty() ? 0 : 1;
+  out->worker_failed = b->failed.load() ? 1 : 0;
   return PEAQ_OK;
 }

@@ -95,6 +95,20 @@ constexpr int kRecSigE      = kRecScalars + 5;   // sum ref^2 over the hop (tota
 constexpr int kRecNoiseE    = kRecScalars + 6;   // sum (ref-test)^2
 constexpr int kRecDoubles   = 576;               // == PEAQ_DEBUG_RECORD_DOUBLES
 
+// stage-level dump of the back end (peaq_debug_backend): per (frame, channel) the patterns the
+// reference's pattern layer hands to the MOV layer
+constexpr int kDbgExcRef       = 0 * kBandStride;   // excitation after time smearing (fftearmodel.c:496-504)
+constexpr int kDbgExcTest      = 1 * kBandStride;
+constexpr int kDbgAdaptRef     = 2 * kBandStride;   // spectrally adapted patterns (leveladapter.c:331-336)
+constexpr int kDbgAdaptTest    = 3 * kBandStride;
+constexpr int kDbgModRef       = 4 * kBandStride;   // modulation (modpatt.c:245-247)
+constexpr int kDbgModTest      = 5 * kBandStride;
+constexpr int kDbgAvgLoudRef   = 6 * kBandStride;   // average loudness (modpatt.c:240-243)
+constexpr int kDbgAvgLoudTest  = 7 * kBandStride;
+constexpr int kDbgLoudnessRef  = 8 * kBandStride;   // total loudness while the gate is closed (earmodel.c:891-907)
+constexpr int kDbgLoudnessTest = 8 * kBandStride + 1;
+constexpr int kDbgDoubles      = 8 * kBandStride + 8;   // == PEAQ_DEBUG_BACKEND_DOUBLES
+
 // filter-bank record per (pair, block, channel): unsmeared/excitation of both
 // signals + above-threshold flag
 constexpr int kFbRecUnsmRef  = 0;

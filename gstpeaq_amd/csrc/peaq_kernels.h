@@ -51,6 +51,7 @@ struct BackendArgs {
   const uint32_t* pair_frame0;
   const uint32_t* pair_nframes;
   const uint32_t* pair_slot;    // state index of pair p (nullptr: p)
+  double* debug;                // basic version only: [pair][frame - frame0][channel][kDbgDoubles], or nullptr
 };
 hipError_t launch_backend(const BackendArgs& a, unsigned n_pairs, hipStream_t stream);
 

@@ -46,6 +46,8 @@ typedef struct _GstPeaqAmd
   peaq_broker *broker;          /* set instead of `session` when the process-wide broker serves this element */
   gint broker_sid;
   gboolean failed;              /* a device error was reported already */
+  gboolean pushed;              /* the current session / broker slot has received samples */
+  gchar *pending_error;         /* set under the object lock, posted after it is released */
 } GstPeaqAmd;
 
 typedef struct _GstPeaqAmdClass
@@ -129,12 +131,16 @@ drop_session (GstPeaqAmd * self)
 }
 
 /* (re)create the engine session: the reference re-allocates all per-channel state
- * whenever caps or the `advanced` property change (gstpeaq.c:519,559,575,586) */
+ * whenever caps or the `advanced` property change (gstpeaq.c:519,559,575,586).
+ * Called with the object lock held: a failure is only RECORDED here
+ * (pending_error); GST_ELEMENT_ERROR takes the same non-recursive lock, so the
+ * callers post it through post_pending_error() after unlocking. */
 static gboolean
 renew_session (GstPeaqAmd * self)
 {
   peaq_ctx *ctx;
   drop_session (self);
+  self->pushed = FALSE;
   if (self->channels <= 0)
     return TRUE;
   if (self->playback_level == 92.) {
@@ -145,14 +151,29 @@ renew_session (GstPeaqAmd * self)
     }
   }
   ctx = shared_context ();
-  if (!ctx)
-    return FALSE;
-  if (peaq_session_create (ctx, self->advanced, self->channels, self->playback_level,
+  if (!ctx || peaq_session_create (ctx, self->advanced, self->channels, self->playback_level,
           &self->session) != PEAQ_OK) {
-    GST_ELEMENT_ERROR (self, LIBRARY, INIT, ("libpeaq_amd: %s", peaq_last_error ()), (NULL));
+    g_free (self->pending_error);
+    self->pending_error = g_strdup_printf ("libpeaq_amd: %s", peaq_last_error ());
+    self->session = NULL;
     return FALSE;
   }
   return TRUE;
+}
+
+/* call WITHOUT the object lock */
+static void
+post_pending_error (GstPeaqAmd * self)
+{
+  gchar *msg;
+  GST_OBJECT_LOCK (self);
+  msg = self->pending_error;
+  self->pending_error = NULL;
+  GST_OBJECT_UNLOCK (self);
+  if (msg) {
+    GST_ELEMENT_ERROR (self, LIBRARY, INIT, ("%s", msg), (NULL));
+    g_free (msg);
+  }
 }
 
 static gboolean
@@ -239,11 +260,22 @@ gst_peaq_amd_set_property (GObject * obj, guint id, const GValue * value, GParam
     case PROP_PLAYBACK_LEVEL:
       GST_OBJECT_LOCK (self);
       self->playback_level = g_value_get_double (value);
-      /* the level enters the constant level factors of both ear models
-       * (fftearmodel.c:305-314, fbearmodel.c:249-254); a running session keeps its level */
-      if ((self->session || self->broker) && self->channels > 0)
-        GST_WARNING_OBJECT (self, "playback_level changed mid-stream: applies from the next (re)negotiation");
+      /* the reference hands the level to both ear models at once (gstpeaq.c:508-515 ->
+       * fftearmodel.c:305-314, fbearmodel.c:249-254): it applies from the next frame on */
+      if (self->session) {
+        if (peaq_session_set_level (self->session, self->playback_level) != PEAQ_OK)
+          GST_WARNING_OBJECT (self, "libpeaq_amd: %s", peaq_last_error ());
+      } else if (self->broker && self->playback_level != 92.) {
+        /* the shared broker runs all its slots at one level: an element that wants another
+         * one gets its own session -- possible as long as its slot has not seen any samples */
+        if (!self->pushed)
+          renew_session (self);
+        else
+          GST_WARNING_OBJECT (self, "playback_level changed mid-stream on a broker-hosted element: "
+              "the new level applies from the next (re)negotiation");
+      }
       GST_OBJECT_UNLOCK (self);
+      post_pending_error (self);
       break;
     case PROP_ADVANCED:
       GST_OBJECT_LOCK (self);
@@ -251,6 +283,7 @@ gst_peaq_amd_set_property (GObject * obj, guint id, const GValue * value, GParam
       if (self->channels > 0)
         renew_session (self);
       GST_OBJECT_UNLOCK (self);
+      post_pending_error (self);
       break;
     case PROP_CONSOLE_OUTPUT:
       self->console_output = g_value_get_boolean (value);
@@ -280,6 +313,7 @@ gst_peaq_amd_chain (GstPad * pad, GstObject * parent, GstBuffer * buffer)
   }
   GST_OBJECT_LOCK (self);               /* the two streaming threads are serialised, gstpeaq.c:619,658 */
   self->eos[idx] = FALSE;
+  self->pushed = TRUE;
   if (self->broker) {
     if (peaq_broker_push (self->broker, self->broker_sid, idx, (const float *) map.data,
             map.size / (sizeof (float) * self->channels)) != PEAQ_OK)
@@ -316,6 +350,7 @@ gst_peaq_amd_set_caps (GstPeaqAmd * self, GstCaps * caps)
     ok = renew_session (self);
   }
   GST_OBJECT_UNLOCK (self);
+  post_pending_error (self);
   return ok;
 }
 
@@ -391,6 +426,7 @@ gst_peaq_amd_finalize (GObject * obj)
 {
   GstPeaqAmd *self = GST_PEAQ_AMD (obj);
   drop_session (self);
+  g_free (self->pending_error);
   G_OBJECT_CLASS (gst_peaq_amd_parent_class)->finalize (obj);
 }
 
@@ -449,6 +485,8 @@ gst_peaq_amd_init (GstPeaqAmd * self)
   self->broker = NULL;
   self->broker_sid = -1;
   self->failed = FALSE;
+  self->pushed = FALSE;
+  self->pending_error = NULL;
 }
 
 static gboolean

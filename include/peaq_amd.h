@@ -102,6 +102,12 @@ int peaq_session_flush (peaq_session *s);
  * reference is preserved. */
 int peaq_session_results (peaq_session *s, peaq_result *out);
 
+/* set_property "playback_level" (gstpeaq.c:508-515 -> fftearmodel.c:305-314,
+ * fbearmodel.c:249-254): applies to every frame processed from now on, state is
+ * kept -- exactly what the reference's ear models do when the property changes
+ * mid-stream. */
+int peaq_session_set_level (peaq_session *s, double playback_level_db);
+
 /* explicit reset (the reference never resets, gstpeaq.c:357-361; the element
  * does not call this) */
 int peaq_session_reset (peaq_session *s);
@@ -194,6 +200,22 @@ int peaq_debug_frontend (peaq_ctx *ctx, int bands, int channels, double playback
 int peaq_debug_filterbank (peaq_ctx *ctx, int channels, double playback_level_db,
                            const float *d_ref, const float *d_test, uint32_t n_ref, uint32_t n_test,
                            int n_blocks, int blocks_per_launch, double *host_out);
+
+/* The stateful back end of the basic version on its own: feeds n_frames front-end
+ * records of ONE pair (host memory, [frame][channel][PEAQ_DEBUG_RECORD_DOUBLES],
+ * e.g. from peaq_debug_frontend or hand-built) through time smearing, level and
+ * pattern adaptation, modulation processing and the MOV layer starting from a
+ * fresh state, and returns per (frame, channel) PEAQ_DEBUG_BACKEND_DOUBLES doubles:
+ *   8 band vectors of 112 -- excitation ref/test (fftearmodel.c:496-504), spectrally
+ *   adapted ref/test (leveladapter.c:243-340), modulation ref/test and average
+ *   loudness ref/test (modpatt.c:223-251) -- then total loudness ref, test
+ *   (earmodel.c:891-907; only written while the loudness gate is still closed).
+ * `result` (may be NULL) receives the MOVs/DI/ODG after the last frame.
+ * Pins the HIP pattern layer against the reference's own known-answer vectors
+ * (testpeaq.c:433-599,748-810). */
+#define PEAQ_DEBUG_BACKEND_DOUBLES 904
+int peaq_debug_backend (peaq_ctx *ctx, int channels, int n_frames, const double *host_records,
+                        double *host_out, peaq_result *result);
 
 #ifdef __cplusplus
 }

@@ -2,7 +2,7 @@
  *
  *   oracle_cli pair  ADV CH REF.f32 TEST.f32   raw interleaved F32LE files
  *   oracle_cli synth ADV CH SEED NSAMPLES      include/peaq_synth.h pair
- *   oracle_cli time  ADV CH SEED0 NPAIRS NSAMPLES   wall-clock of NPAIRS pairs (1 thread)
+ *   oracle_cli time  ADV CH SEED0 NPAIRS NSAMPLES [REPEATS START_EPOCH]   wall-clock of NPAIRS pairs (1 thread)
  * Prints the same JSON shape as oracle/ref_harness.c so the two can be diffed.
  */
 #include <stdio.h>
@@ -91,32 +91,64 @@ main (int argc, char **argv)
     return 0;
   }
   if (argc >= 7 && !strcmp (argv[1], "time")) {
+    /* same arguments and JSON shape as `ref_harness time` (see there) */
     int adv = atoi (argv[2]), ch = atoi (argv[3]);
     uint32_t seed0 = (uint32_t) strtoul (argv[4], NULL, 0);
-    int np = atoi (argv[5]), p;
+    int np = atoi (argv[5]), p, rep;
     uint32_t ns = (uint32_t) strtoul (argv[6], NULL, 0);
-    float *r = malloc ((size_t) ns * ch * 4), *t = malloc ((size_t) ns * ch * 4);
-    double total = 0., odg_sum = 0.;
+    int repeats = argc >= 9 ? atoi (argv[7]) : 0;
+    double start_epoch = argc >= 9 ? atof (argv[8]) : 0.;
+    size_t per = (size_t) ns * ch;
+    float *r = malloc (per * 4 * (repeats ? np : 1)), *t = malloc (per * 4 * (repeats ? np : 1));
+    double *movs = calloc (11 * (size_t) np, sizeof (double)), *di = malloc (sizeof (double) * np),
+      *odg = malloc (sizeof (double) * np);
+    double total = 0., t_begin = 0., t_end = 0.;
     unsigned frames = 0;
+    struct timespec a, b;
     for (p = 0; p < np; p++) {
-      struct timespec a, b;
-      double movs[11], di, odg;
       orc_session *s;
-      peaq_synth_pair (seed0 + p, ch, ns, r, t);      /* generation is not timed */
+      float *rp = r + (repeats ? p * per : 0), *tp = t + (repeats ? p * per : 0);
+      peaq_synth_pair (seed0 + p, ch, ns, rp, tp);      /* generation is not timed */
+      if (repeats)
+        continue;
       clock_gettime (CLOCK_MONOTONIC, &a);
       s = orc_session_new (adv, ch, 92.);
-      orc_session_push_ref (s, r, ns);
-      orc_session_push_test (s, t, ns);
+      orc_session_push_ref (s, rp, ns);
+      orc_session_push_test (s, tp, ns);
       orc_session_flush (s);
-      orc_session_results (s, movs, &di, &odg);
+      orc_session_results (s, movs + 11 * p, di + p, odg + p);
       clock_gettime (CLOCK_MONOTONIC, &b);
       frames += orc_session_frames (s);
       orc_session_free (s);
       total += (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec);
-      odg_sum += odg;
     }
-    printf ("{\"pairs\": %d, \"frame_pairs\": %u, \"seconds\": %.6f, \"frame_pairs_per_s\": %.1f, "
-            "\"odg_mean\": %.6f}\n", np, frames, total, frames / total, odg_sum / np);
+    if (repeats) {
+      do
+        clock_gettime (CLOCK_REALTIME, &a);
+      while (a.tv_sec + 1e-9 * a.tv_nsec < start_epoch);
+      t_begin = a.tv_sec + 1e-9 * a.tv_nsec;
+      for (rep = 0; rep < repeats; rep++)
+        for (p = 0; p < np; p++) {
+          double m[11], d, o;
+          orc_session *s = orc_session_new (adv, ch, 92.);
+          orc_session_push_ref (s, r + p * per, ns);
+          orc_session_push_test (s, t + p * per, ns);
+          orc_session_flush (s);
+          orc_session_results (s, rep ? m : movs + 11 * p, rep ? &d : di + p, rep ? &o : odg + p);
+          frames += orc_session_frames (s);
+          orc_session_free (s);
+        }
+      clock_gettime (CLOCK_REALTIME, &b);
+      t_end = b.tv_sec + 1e-9 * b.tv_nsec;
+      total = t_end - t_begin;
+    }
+    printf ("{\"pairs\": %d, \"repeats\": %d, \"frame_pairs\": %u, \"seconds\": %.6f, \"frame_pairs_per_s\": %.1f, "
+            "\"t_begin\": %.6f, \"t_end\": %.6f, \"n_movs\": %d, ", np, repeats, frames, total, frames / total,
+            t_begin, t_end, adv ? 5 : 11);
+    print_arr ("odg", odg, np, 0);
+    print_arr ("di", di, np, 0);
+    print_arr ("movs", movs, 11 * np, 1);
+    printf ("}\n");
     return 0;
   }
   fprintf (stderr, "usage: see the header of oracle/oracle_cli.c\n");

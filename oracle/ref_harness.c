@@ -11,7 +11,9 @@
  *   ref_harness pair  ADV CH REF.f32 TEST.f32     raw interleaved F32LE files
  *   ref_harness synth ADV CH SEED NSAMPLES        include/peaq_synth.h pair
  *   ref_harness launch ADV "<gst-launch fragment feeding peaq.ref / peaq.test>"
- *   ref_harness time ADV CH SEED0 NPAIRS NSAMPLES  wall-clock of the element on NPAIRS synth pairs
+ *   ref_harness time ADV CH SEED0 NPAIRS NSAMPLES [REPEATS START_EPOCH]
+ *                                              wall-clock of the element on NPAIRS synth pairs, with their MOVs/DI/ODG;
+ *                                              REPEATS > 0: one timed region that starts at START_EPOCH (all-core runs)
  *   (environment REF_PLAYBACK_LEVEL=<dB> sets the element's playback_level in pair / synth / launch)
  *   ref_harness fftear BANDS FILE.f32             per-frame ear-model dumps (mono, hop 1024)
  *   ref_harness fbear FILE.f32                    per-block filter-bank dumps (mono, 192)
@@ -112,57 +114,123 @@ now_s (void)
   return t.tv_sec + 1e-9 * t.tv_nsec;
 }
 
-/* CPU baseline: the real element, fed from page-cached raw files; generation of
- * the inputs is not timed, pipeline construction/teardown is (a few ms). */
+/* One pair through the real element: builds the pipeline, plays it to EOS, reads MOVs/DI/ODG. */
 static int
-time_pairs (int advanced, int channels, uint32_t seed0, int n_pairs, uint32_t ns)
+run_timed_pair (int advanced, const char *desc, double *movs, double *di, double *odg, unsigned *frames)
+{
+  GError *err = NULL;
+  GstElement *pipe, *peaq_el;
+  GstBus *bus;
+  GstMessage *msg;
+  GstPeaq *pq;
+  int i, n = advanced ? COUNT_MOV_ADVANCED : COUNT_MOV_BASIC;
+  pipe = gst_parse_launch (desc, &err);
+  if (!pipe) return 2;
+  peaq_el = gst_bin_get_by_name (GST_BIN (pipe), "peaq");
+  g_object_set (peaq_el, "advanced", advanced, "console-output", FALSE, NULL);
+  gst_element_set_state (pipe, GST_STATE_PLAYING);
+  bus = gst_element_get_bus (pipe);
+  msg = gst_bus_timed_pop_filtered (bus, GST_CLOCK_TIME_NONE, GST_MESSAGE_EOS | GST_MESSAGE_ERROR);
+  if (GST_MESSAGE_TYPE (msg) == GST_MESSAGE_ERROR) return 3;
+  gst_message_unref (msg);
+  gst_object_unref (bus);
+  gst_element_set_state (pipe, GST_STATE_NULL);
+  pq = GST_PEAQ (peaq_el);
+  for (i = 0; i < COUNT_MOV_BASIC; i++)
+    movs[i] = i < n ? peaq_movaccum_get_value (pq->mov_accum[i]) : 0.;
+  g_object_get (peaq_el, "di", di, "odg", odg, NULL);
+  *frames = pq->frame_counter;
+  gst_object_unref (peaq_el);
+  gst_object_unref (pipe);
+  return 0;
+}
+
+static double
+epoch_s (void)
+{
+  struct timespec t;
+  clock_gettime (CLOCK_REALTIME, &t);
+  return t.tv_sec + 1e-9 * t.tv_nsec;
+}
+
+/* CPU baseline: the real element, fed from page-cached raw files; generation of
+ * the inputs is not timed, pipeline construction/teardown is (a few ms).
+ * repeats == 0: NPAIRS distinct pairs, each generated and then timed on its own
+ *   (sum of the per-pair times).
+ * repeats  > 0: NPAIRS distinct pairs are generated first, then -- from the wall
+ *   clock instant start_epoch on, so that many such processes (one per core) run
+ *   their timed regions together -- the set is processed `repeats` times in one
+ *   timed region.  The JSON carries the region's begin/end on the CLOCK_REALTIME
+ *   axis for the parent to aggregate.
+ * Either way the MOVs / DI / ODG of the first pass over each pair are printed. */
+static int
+time_pairs (int advanced, int channels, uint32_t seed0, int n_pairs, uint32_t ns, int repeats, double start_epoch)
 {
   float *r = malloc ((size_t) ns * channels * 4), *t = malloc ((size_t) ns * channels * 4);
   char fr[256], ft[256], desc[2048];
-  double total = 0.;
+  double total = 0., t_begin = 0., t_end = 0.;
+  double *movs = malloc (sizeof (double) * COUNT_MOV_BASIC * n_pairs);
+  double *di = malloc (sizeof (double) * n_pairs), *odg = malloc (sizeof (double) * n_pairs);
   unsigned frames = 0;
-  int p, saved_out;
-  snprintf (fr, sizeof fr, "/tmp/refh_%d_r.f32", (int) getpid ());
-  snprintf (ft, sizeof ft, "/tmp/refh_%d_t.f32", (int) getpid ());
-  snprintf (desc, sizeof desc,
-            "filesrc location=%s ! rawaudioparse format=pcm pcm-format=f32le sample-rate=48000 "
-            "num-channels=%d ! peaq.ref "
-            "filesrc location=%s ! rawaudioparse format=pcm pcm-format=f32le sample-rate=48000 "
-            "num-channels=%d ! peaq.test peaq name=peaq", fr, channels, ft, channels);
+  int p, rep, rc, n = advanced ? COUNT_MOV_ADVANCED : COUNT_MOV_BASIC;
   for (p = 0; p < n_pairs; p++) {
     FILE *f;
     double t0;
-    GError *err = NULL;
-    GstElement *pipe, *peaq_el;
-    GstBus *bus;
-    GstMessage *msg;
-    double odg;
+    unsigned fc;
+    snprintf (fr, sizeof fr, "/tmp/refh_%d_%d_r.f32", (int) getpid (), repeats ? p : 0);
+    snprintf (ft, sizeof ft, "/tmp/refh_%d_%d_t.f32", (int) getpid (), repeats ? p : 0);
     peaq_synth_pair (seed0 + p, channels, ns, r, t);
     f = fopen (fr, "wb"); fwrite (r, 4, (size_t) ns * channels, f); fclose (f);
     f = fopen (ft, "wb"); fwrite (t, 4, (size_t) ns * channels, f); fclose (f);
+    if (repeats)
+      continue;
+    snprintf (desc, sizeof desc,
+              "filesrc location=%s ! rawaudioparse format=pcm pcm-format=f32le sample-rate=48000 "
+              "num-channels=%d ! peaq.ref "
+              "filesrc location=%s ! rawaudioparse format=pcm pcm-format=f32le sample-rate=48000 "
+              "num-channels=%d ! peaq.test peaq name=peaq", fr, channels, ft, channels);
     t0 = now_s ();
-    pipe = gst_parse_launch (desc, &err);
-    if (!pipe) return 2;
-    peaq_el = gst_bin_get_by_name (GST_BIN (pipe), "peaq");
-    g_object_set (peaq_el, "advanced", advanced, "console-output", FALSE, NULL);
-    gst_element_set_state (pipe, GST_STATE_PLAYING);
-    bus = gst_element_get_bus (pipe);
-    msg = gst_bus_timed_pop_filtered (bus, GST_CLOCK_TIME_NONE, GST_MESSAGE_EOS | GST_MESSAGE_ERROR);
-    if (GST_MESSAGE_TYPE (msg) == GST_MESSAGE_ERROR) return 3;
-    gst_message_unref (msg);
-    gst_object_unref (bus);
-    gst_element_set_state (pipe, GST_STATE_NULL);
-    g_object_get (peaq_el, "odg", &odg, NULL);
+    rc = run_timed_pair (advanced, desc, movs + p * COUNT_MOV_BASIC, di + p, odg + p, &fc);
+    if (rc) return rc;
     total += now_s () - t0;
-    frames += GST_PEAQ (peaq_el)->frame_counter;
-    gst_object_unref (peaq_el);
-    gst_object_unref (pipe);
+    frames += fc;
   }
-  (void) saved_out;
-  remove (fr);
-  remove (ft);
-  printf ("{\"pairs\": %d, \"frame_pairs\": %u, \"seconds\": %.6f, \"frame_pairs_per_s\": %.1f}\n",
-          n_pairs, frames, total, frames / total);
+  if (repeats) {
+    while (epoch_s () < start_epoch)
+      usleep (200);
+    t_begin = epoch_s ();
+    for (rep = 0; rep < repeats; rep++)
+      for (p = 0; p < n_pairs; p++) {
+        double m[COUNT_MOV_BASIC], d, o;
+        unsigned fc;
+        snprintf (fr, sizeof fr, "/tmp/refh_%d_%d_r.f32", (int) getpid (), p);
+        snprintf (ft, sizeof ft, "/tmp/refh_%d_%d_t.f32", (int) getpid (), p);
+        snprintf (desc, sizeof desc,
+                  "filesrc location=%s ! rawaudioparse format=pcm pcm-format=f32le sample-rate=48000 "
+                  "num-channels=%d ! peaq.ref "
+                  "filesrc location=%s ! rawaudioparse format=pcm pcm-format=f32le sample-rate=48000 "
+                  "num-channels=%d ! peaq.test peaq name=peaq", fr, channels, ft, channels);
+        rc = run_timed_pair (advanced, desc, rep ? m : movs + p * COUNT_MOV_BASIC, rep ? &d : di + p,
+                             rep ? &o : odg + p, &fc);
+        if (rc) return rc;
+        frames += fc;
+      }
+    t_end = epoch_s ();
+    total = t_end - t_begin;
+  }
+  for (p = 0; p < (repeats ? n_pairs : 1); p++) {
+    snprintf (fr, sizeof fr, "/tmp/refh_%d_%d_r.f32", (int) getpid (), p);
+    snprintf (ft, sizeof ft, "/tmp/refh_%d_%d_t.f32", (int) getpid (), p);
+    remove (fr);
+    remove (ft);
+  }
+  printf ("{\"pairs\": %d, \"repeats\": %d, \"frame_pairs\": %u, \"seconds\": %.6f, \"frame_pairs_per_s\": %.1f, "
+          "\"t_begin\": %.6f, \"t_end\": %.6f, \"n_movs\": %d, ", n_pairs, repeats, frames, total, frames / total,
+          t_begin, t_end, n);
+  print_arr ("odg", odg, n_pairs, 0);
+  print_arr ("di", di, n_pairs, 0);
+  print_arr ("movs", movs, n_pairs * COUNT_MOV_BASIC, 1);
+  printf ("}\n");
   return 0;
 }
 
@@ -282,7 +350,8 @@ main (int argc, char **argv)
   }
   if (argc >= 7 && !strcmp (argv[1], "time"))
     return time_pairs (atoi (argv[2]), atoi (argv[3]), (uint32_t) strtoul (argv[4], NULL, 0), atoi (argv[5]),
-                       (uint32_t) strtoul (argv[6], NULL, 0));
+                       (uint32_t) strtoul (argv[6], NULL, 0), argc >= 9 ? atoi (argv[7]) : 0,
+                       argc >= 9 ? atof (argv[8]) : 0.);
   if (argc >= 4 && !strcmp (argv[1], "launch"))
     return run_pipeline (atoi (argv[2]), argv[3]);
   if (argc >= 4 && !strcmp (argv[1], "fftear"))

@@ -1,0 +1,124 @@
+"""Stage-level parity of the HIP pattern layer: the stateful back end
+is driven on its own through peaq_debug_backend and compared
+  * with the reference's OWN known-answer vectors for the level adapter and the modulation
+    processor (testpeaq.c:433-599, test_leveladapt :748-784, test_modulationproc :787-810;
+    extracted as data to tests/golden/testpeaq_vectors.json), with the reference's tolerance
+    (rel 5e-5 or abs 5e-6, testpeaq.c:33-35,606-621), and
+  * frame by frame with the oracle's ear model -> level adapter / modulation processor on two
+    golden signal pairs (rtol 1e-9).
+Needs an MI355X (`-m gpu`); everything goes through the C ABI."""
+import json
+
+import numpy as np
+import pytest
+
+import cases as case_defs
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+
+NB = 109
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (there is no CPU fallback in the product)")
+    import gpu_common
+    return gpu_common
+
+
+@pytest.fixture(scope="module")
+def tp(golden_dir):
+    return json.loads((golden_dir / "testpeaq_vectors.json").read_text())
+
+
+def assert_testpeaq_close(got, exp, tol):
+    got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+    err = np.abs(got - exp)
+    ok = (err <= tol["rel"] * np.abs(exp)) | (err <= tol["abs"])
+    assert ok.all(), (np.flatnonzero(~ok)[:5], got[~ok][:5], exp[~ok][:5])
+
+
+def hand_records(n_frames, unsm_ref, unsm_test):
+    """front-end records carrying the given unsmeared excitation patterns (and their ^0.3, which the
+    front end computes for the modulation processor, modpatt.c:235); everything else neutral"""
+    rec = np.zeros((n_frames, 1, 576))
+    rec[:, 0, 0:NB] = unsm_ref
+    rec[:, 0, 112:112 + NB] = unsm_test
+    rec[:, 0, 224:224 + NB] = np.asarray(unsm_ref, dtype=np.float64) ** 0.3
+    rec[:, 0, 336:336 + NB] = np.asarray(unsm_test, dtype=np.float64) ** 0.3
+    rec[:, 0, 448:448 + NB] = 1.0        # noise in bands
+    rec[:, 0, 563] = 3.0                 # flags: above threshold + energy (ref)
+    rec[:, 0, 564] = 2.0
+    return rec
+
+
+def test_level_adapter_against_testpeaq_vectors(gpu, tp):
+    """testpeaq.c:748-784: ref = i + 1, test = 109 - i, two calls.  Fed as unsmeared excitation: with the
+    smearing filter starting from zero (fftearmodel.c:319-322) a constant input passes the max() of
+    :501-503 unchanged, so the level adapter sees exactly the reference test's input."""
+    import gstpeaq_amd.capi as capi
+    ref = np.arange(1, NB + 1, dtype=np.float64)
+    test = np.arange(NB, 0, -1, dtype=np.float64)
+    d, _ = capi.debug_backend(gpu.ctx(), hand_records(2, ref, test))
+    np.testing.assert_array_equal(d["exc_ref"][0, 0], ref)
+    np.testing.assert_array_equal(d["exc_test"][1, 0], test)
+    tol = tp["_tolerance"]
+    assert_testpeaq_close(d["adapted_ref"][0, 0], tp["spectrally_adapted_ref_patterns1_ref"], tol)
+    assert_testpeaq_close(d["adapted_test"][0, 0], tp["spectrally_adapted_test_patterns1_ref"], tol)
+    assert_testpeaq_close(d["adapted_ref"][1, 0], tp["spectrally_adapted_ref_patterns2_ref"], tol)
+    assert_testpeaq_close(d["adapted_test"][1, 0], tp["spectrally_adapted_test_patterns2_ref"], tol)
+
+
+def test_modulation_processor_against_testpeaq_vectors(gpu, tp):
+    """testpeaq.c:787-810: input i + 1, two calls -> modulation and average loudness"""
+    import gstpeaq_amd.capi as capi
+    x = np.arange(1, NB + 1, dtype=np.float64)
+    d, _ = capi.debug_backend(gpu.ctx(), hand_records(2, x, x))
+    tol = tp["_tolerance"]
+    for sig in ("ref", "test"):
+        assert_testpeaq_close(d[f"mod_{sig}"][0, 0], tp["modulation1_ref"], tol)
+        assert_testpeaq_close(d[f"avgloud_{sig}"][0, 0], tp["loudness1_ref"], tol)
+        assert_testpeaq_close(d[f"mod_{sig}"][1, 0], tp["modulation2_ref"], tol)
+        assert_testpeaq_close(d[f"avgloud_{sig}"][1, 0], tp["loudness2_ref"], tol)
+
+
+@pytest.mark.parametrize("case", [
+    dict(kind="synth", seed=12, channels=1, n=72000),                         # golden case synth_s12_mono
+    dict(kind="ats", wave_ref="saw", wave_test="triangle", n=65536, channels=1),   # runtest-1.0.sh pipeline 2
+], ids=["synth_s12_mono", "ats_saw_triangle"])
+def test_backend_patterns_match_oracle_per_frame(gpu, case):
+    """HIP front end -> HIP back end vs the oracle's ear model -> level adapter / modulation processor,
+    every frame: excitation (time smearing), adapted patterns, modulation, average loudness, and the
+    total loudness of the frames before the loudness gate opens"""
+    import torch
+    import gstpeaq_amd
+    import gstpeaq_amd.capi as capi
+    ref, test = case_defs.make_inputs(case)
+    n_frames = (len(ref) - 2048) // 1024 + 1
+    recs = gstpeaq_amd.debug_frontend(gpu.ctx(), NB, torch.from_numpy(ref).cuda(), torch.from_numpy(test).cuda(),
+                                      n_frames)
+    d, res = capi.debug_backend(gpu.ctx(), recs)
+    o_ref = orc.fftear(NB, ref[:, 0], n_frames, 1024)
+    o_test = orc.fftear(NB, test[:, 0], n_frames, 1024)
+    np.testing.assert_allclose(d["exc_ref"][:, 0], o_ref["excitation"], rtol=1e-9)
+    np.testing.assert_allclose(d["exc_test"][:, 0], o_test["excitation"], rtol=1e-9)
+    ad_r, ad_t = orc.leveladapt(NB, o_ref["excitation"], o_test["excitation"])
+    np.testing.assert_allclose(d["adapted_ref"][:, 0], ad_r, rtol=1e-9)
+    np.testing.assert_allclose(d["adapted_test"][:, 0], ad_t, rtol=1e-9)
+    for sig, o in (("ref", o_ref), ("test", o_test)):
+        mod, loud = orc.modproc(NB, o["unsmeared"])
+        np.testing.assert_allclose(d[f"mod_{sig}"][:, 0], mod, rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(d[f"avgloud_{sig}"][:, 0], loud, rtol=1e-9)
+    # total loudness is only evaluated until the gate opens (gstpeaq.c:841-845)
+    gate = np.flatnonzero((o_ref["loudness"] > 0.1) & (o_test["loudness"] > 0.1))
+    upto = (gate[0] + 1) if gate.size else n_frames
+    np.testing.assert_allclose(d["loudness"][:upto, 0, 0], o_ref["loudness"][:upto], rtol=1e-9)
+    np.testing.assert_allclose(d["loudness"][:upto, 0, 1], o_test["loudness"][:upto], rtol=1e-9)
+    # and the MOVs of the frames fed equal a whole-pair run truncated to the same frames
+    exp = orc.run_pair(0, ref[: (n_frames - 1) * 1024 + 2048], test[: (n_frames - 1) * 1024 + 2048])
+    assert res["frames"] == exp["frames"] == n_frames
+    np.testing.assert_allclose(res["movs"], exp["movs"], rtol=1e-7, atol=1e-9)
+    assert abs(res["odg"] - exp["odg"]) < 1e-6

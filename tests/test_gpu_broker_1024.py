@@ -1,0 +1,72 @@
+"""BASELINE.json configs[4] at its stated size: 1024 concurrent live (ref, test) streams through the
+broker, fed by a NATIVE feeder (tools/broker_feeder.cpp: 16 threads on the C ABI, what a process
+hosting that many `peaq` elements does in pad_chain, reference gstpeaq.c:614-661) -- every session's
+result must equal the batch path's on the same seeded pair, and the broker must really have batched
+(>= 512 sessions served by one launch).  Plus ONE gst-launch process hosting 256 `peaq` elements on
+the shared broker.  Needs an MI355X (`-m gpu`)."""
+import json
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+FEEDER = ROOT / "tools" / "broker_feeder"
+
+
+def run_feeder(*args):
+    if not FEEDER.exists():
+        subprocess.run(["make", "-C", str(ROOT / "tools")], check=True, capture_output=True)
+    out = subprocess.run([str(FEEDER), *map(str, args)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-1500:])
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_1024_live_sessions_basic_equal_batch():
+    d = run_feeder("--sessions", 1024, "--seconds", 2.0, "--threads", 16, "--chunk", 4096)
+    assert d["mismatches"] == 0 and d["feed_errors"] == 0 and d["worker_failed"] == 0
+    assert d["max_abs_dodg_vs_batch"] == 0.0                    # bit-equal in the basic version
+    assert d["max_active"] >= 512, d
+    assert d["frame_pairs"] == 1024 * 93                        # 2 s: 92 full frames + the flush frame
+    print("broker 1024 basic:", d)
+
+
+def test_1024_live_sessions_ragged_buffers():
+    """every session pushes its own buffer size (480..5479 samples): frame boundaries never line up"""
+    d = run_feeder("--sessions", 1024, "--seconds", 1.0, "--threads", 8, "--ragged")
+    assert d["mismatches"] == 0 and d["feed_errors"] == 0 and d["worker_failed"] == 0
+    assert d["max_active"] >= 512, d
+
+
+def test_1024_live_sessions_advanced():
+    d = run_feeder("--sessions", 1024, "--seconds", 1.0, "--threads", 16, "--advanced")
+    assert d["mismatches"] == 0 and d["feed_errors"] == 0 and d["worker_failed"] == 0
+    assert d["max_abs_dodg_vs_batch"] < 1e-6
+    assert d["max_active"] >= 512, d
+    print("broker 1024 advanced:", d)
+
+
+def test_one_gst_process_hosts_256_elements_on_the_broker():
+    """256 `peaq` elements (512 streaming threads) in ONE gst-launch process share one broker; the
+    reference's two regression pipelines alternate, so half must print ODG 0.171 and half -2.007
+    (runtest-1.0.sh:18,28), exactly as one element per process does"""
+    import gst_env
+    if not gst_env.have_gst():
+        pytest.fail("GStreamer tools / built plugin missing on the GPU box")
+    n = 256
+    args = []
+    for i in range(n):
+        waves = ("sine", "sine") if i % 2 == 0 else ("saw", "triangle")
+        args += ["audiotestsrc", f"name=s{i}", "num-buffers=128", f"wave={waves[0]}", "freq=440",
+                 "audiotestsrc", f"name=r{i}", "num-buffers=128", f"wave={waves[1]}", "freq=440",
+                 "peaq", f"name=p{i}", f"s{i}.src!p{i}.ref", f"r{i}.src!p{i}.test"]
+    env = gst_env.env()
+    env["PEAQ_AMD_BROKER"] = "256"
+    out = subprocess.run(["gst-launch-1.0", "-q", f"--gst-plugin-load={gst_env.PLUGIN}", *args],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    odgs = re.findall(r"Objective Difference Grade: (-?[0-9.]+|-?nan)", out.stdout)
+    assert sorted(odgs) == sorted(["0.171"] * (n // 2) + ["-2.007"] * (n // 2)), (len(odgs), sorted(set(odgs)))
