@@ -91,24 +91,47 @@ def cpu_single(n_samples, channels, seed0, advanced, budget_s):
     return base, d
 
 
-def cpu_all_cores(n_samples, channels, seed0, advanced, pair_seconds, budget_s=6.0):
-    """One process per host core, each pushing its own seeded pairs through the element; the timed
-    regions start together (wall-clock rendezvous); value = all frame-pairs / (last end - first begin)."""
-    tool, kind, what = _cpu_tool()
+def _cpu_limit():
+    """(usable cores, note): the affinity mask, cut down to the container's CPU quota if it has one
+    (cgroup v2 cpu.max / v1 cfs quota) -- more busy processes than that only time-slice."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None and quota < cores:
+        return max(1, int(quota)), f"container CPU quota {quota:g} of {cores} visible cores"
+    return cores, None
+
+
+def cpu_all_cores(n_samples, channels, seed0, advanced, budget_s=8.0):
+    """One process per usable host core, each pushing its own seeded pairs through the element over and
+    over for `budget_s` seconds; the timed regions start together (wall-clock rendezvous);
+    value = all frame-pairs / (last end - first begin)."""
+    tool, kind, what = _cpu_tool()
+    cores, note = _cpu_limit()
     distinct = 2
-    repeats = max(1, int(math.ceil(budget_s / (distinct * pair_seconds))))
-    start = time.time() + 6.0 + cores * 0.01               # generation (~0.3 s per pair) + process start-up
+    start = time.time() + 5.0 + cores * 0.02               # generation (~0.3 s per pair) + process start-up
     procs = [subprocess.Popen([tool, "time", str(int(advanced)), str(channels), str(seed0 + 100000 + distinct * i),
-                               str(distinct), str(n_samples), str(repeats), f"{start:.3f}"],
+                               str(distinct), str(n_samples), str(-int(budget_s)), f"{start:.3f}"],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(cores)]
     res = []
+    deadline = start + budget_s + 120.0
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=300)
+            out, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
             if p.returncode == 0:
                 res.append(json.loads(out.strip().splitlines()[-1].replace('"nan"', "NaN")))
         except Exception:
@@ -120,8 +143,9 @@ def cpu_all_cores(n_samples, channels, seed0, advanced, pair_seconds, budget_s=6
     late = sum(1 for r in res if r["t_begin"] > start + 0.25)
     return dict(value=frames / wall, unit="frame-pairs/s", cores=len(res), nproc=os.cpu_count(), cpu_model=_cpu_model(),
                 kind=kind,
-                sample=f"{len(res)} processes (one per core) x {distinct} seeded pairs x {repeats} passes = {frames} "
-                       f"frame-pairs through {what}, timed regions started together, {wall:.1f} s wall"
+                sample=f"{len(res)} processes (one per usable core) looping over {distinct} seeded pairs each for "
+                       f"{budget_s:g} s = {frames} frame-pairs through {what}, timed regions started together, "
+                       f"{wall:.1f} s wall" + (f"; {note}" if note else "")
                        + (f" ({late} processes started late)" if late else ""))
 
 
@@ -371,8 +395,7 @@ def main():
             line["cpu_baseline"] = base
             line.update(result_deltas(rows_main, cpu, main_adv))
             line["delta_vs"] = base["kind"]
-            pair_s = cpu["seconds"] / max(cpu["pairs"], 1)
-            allc = cpu_all_cores(n_samples, args.channels, seed_base + lo, main_adv, pair_s)
+            allc = cpu_all_cores(n_samples, args.channels, seed_base + lo, main_adv)
             if allc:
                 line["cpu_baseline"]["all_cores"] = allc
             if adv is not None:

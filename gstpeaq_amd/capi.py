@@ -37,7 +37,9 @@ class _BrokerStats(C.Structure):
 
 
 def library_path():
-    return PKG / "libpeaq_amd.so"
+    # PEAQ_AMD_LIB: development knob for A/B runs of kernel variants (tools/variants.sh); the
+    # product is the in-tree libpeaq_amd.so
+    return Path(os.environ["PEAQ_AMD_LIB"]) if os.environ.get("PEAQ_AMD_LIB") else PKG / "libpeaq_amd.so"
 
 
 def build_library(verbose=False):

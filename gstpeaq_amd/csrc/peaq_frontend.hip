@@ -42,10 +42,27 @@ namespace peaq {
 // LDS per wave ("unit"): 1288 doubles = 10304 B.  During the FFT the first 1088 doubles are the
 // exchange buffer (one real component of the 1024 complex points at a time, padded); afterwards
 // Pw[0..775] (weighted power spectrum) followed by 512 doubles of scratch.
+#ifdef PEAQ_FE_W4
+// four waves per SIMD = eight workgroups per CU: at most 20480 B of LDS per workgroup
+constexpr int kPwLen = 769;                   // the last band ends at bin 768 (18 kHz)
+constexpr int kOffPw = 0;
+constexpr int kOffScratch = kPwLen;
+constexpr int kUnitDoubles = kPwLen + 512;    // reference unit: 512 doubles of scratch
+constexpr int kUnit1Doubles = kPwLen + 368;   // test unit: 368 (spreading accumulators + band powers)
+constexpr int kLdsDoubles = kUnitDoubles + kUnit1Doubles;
+constexpr int kWavesPerSimd = 4;
+constexpr bool kEhsTwoBuffers = false;
+static_assert(kUnit1Doubles >= 1088, "the FFT exchange buffer must fit");
+static_assert(kLdsDoubles * 8 <= 20480, "eight workgroups per CU");
+#else
 constexpr int kUnitDoubles = 1288;
 constexpr int kOffPw = 0;                     // Pw[776]
 constexpr int kOffScratch = 776;              // 512 doubles
 constexpr int kPwLen = 776;
+constexpr int kLdsDoubles = 2 * kUnitDoubles;
+constexpr int kWavesPerSimd = 3;
+constexpr bool kEhsTwoBuffers = true;
+#endif
 
 // W_32^q = exp(-2 pi i q / 32), q = 0..15
 __device__ constexpr double kW32re[16] = {1., 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
@@ -81,7 +98,7 @@ __device__ __forceinline__ void exchange16(cplx (&z)[16], double* buf, WR wr, RD
 
 // ---------------------------------------------------------------------------
 // 2048-point real DFT of one frame held as z[r] = x[2n] + i x[2n+1], n = lane + 64 r.
-// On return p[q] is the power spectrum at bin lane + 64 q (registers) and Pw of the unit
+// On return p[s] is the power spectrum at bin spec_bin(s, lane) (registers) and Pw of the unit
 // holds the weighted power spectrum of bins 0..775.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double (&p)[16], double* unit, int lane,
@@ -131,27 +148,48 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double (&p)[
     z[m + 12] = cmul(z[m + 12], w3);
     dft4(z[m], z[m + 4], z[m + 8], z[m + 12]);
   }
-  // z[q] = Z[lane + 64 q].  The even/odd split needs the mirror bin Z[1024 - k]: it lives in
-  // lane 64 - lane, slot 15 - q (lane 0: own slot 16 - q, and Z[1024] = Z[0]) -- a lane
-  // permutation, done bin by bin through the crossbar so that no extra registers pile up.
-  // X[k] = E[k] + W_2048^k O[k], k = lane + 64 q; W_2048^k = W_2048^lane * W_32^q, the second
-  // factor is a compile-time constant.
+  // z[q] = Z[lane + 64 q].  Even/odd split, two bins per step: with E = (Z[k] + conj Z[1024-k]) / 2,
+  // O = (Z[k] - conj Z[1024-k]) / 2i the real signal's spectrum is X[k] = E + W_2048^k O and
+  // X[1024-k] = conj(E - W_2048^k O), so a lane that owns k = lane + 64 q (q = 0..7) also produces
+  // the power of the mirror bin 1024 - k from the same E and O.  Z[1024-k] lives in lane 64 - lane,
+  // slot 15 - q (lane 0: own slot 16 - q, Z[1024] = Z[0]) -- a lane permutation, done bin by bin
+  // through the crossbar.  The halvings are exact and folded into the level factor.
+  // W_2048^k = W_2048^lane * W_32^q, the second factor is a compile-time constant.
+  // Slot q of p[] holds bin lane + 64 q, slot 8 + q the mirror bin (spec_bin() below); lane 0's
+  // q = 0 mirror would be bin 1024, which nothing reads: it carries the self-mirrored bin 512.
   wave_lds_fence();                                  // the exchange buffer is about to become Pw
   const cplx wl = {ct->tw_re[lane], ct->tw_im[lane]};
   const int partner = (64 - lane) & 63;
+  const double lf4 = 0.25 * level_factor;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
+  for (int q = 0; q < 8; ++q) {
     const int k = lane + 64 * q;
     cplx zm = {__shfl(z[15 - q].re, partner, 64), __shfl(z[15 - q].im, partner, 64)};
     if (lane == 0) zm = z[(16 - q) & 15];
-    const cplx e = {0.5 * (z[q].re + zm.re), 0.5 * (z[q].im - zm.im)};
-    const cplx o = {0.5 * (z[q].im + zm.im), -0.5 * (z[q].re - zm.re)};
+    const cplx e2 = {z[q].re + zm.re, z[q].im - zm.im};               // 2 E
+    const cplx o2 = {z[q].im + zm.im, zm.re - z[q].re};               // 2 O
     const cplx wq = {kW32re[q], kW32im[q]};
-    const cplx x = cadd(e, cmul(q == 0 ? wl : cmul(wl, wq), o));
-    p[q] = (x.re * x.re + x.im * x.im) * level_factor;               // fftearmodel.c:464-466
-    if (k < kPwLen) unit[kOffPw + k] = p[q] * ct->ear_w2[k];          // fftearmodel.c:470-472
+    const cplx t = cmul(q == 0 ? wl : cmul(wl, wq), o2);
+    const cplx xp = cadd(e2, t), xm = csub(e2, t);
+    p[q] = (xp.re * xp.re + xp.im * xp.im) * lf4;                     // fftearmodel.c:464-466
+    double pm = (xm.re * xm.re + xm.im * xm.im) * lf4;
+    int km = 1024 - k;
+    if (q == 0 && lane == 0) {                                        // bin 512 = conj Z[512]
+      pm = (z[8].re * z[8].re + z[8].im * z[8].im) * level_factor;
+      km = 512;
+    }
+    p[8 + q] = pm;
+    unit[kOffPw + k] = p[q] * ct->ear_w2[k];                          // fftearmodel.c:470-472
+    if (km < kPwLen) unit[kOffPw + km] = pm * ct->ear_w2[km];
   }
   wave_lds_fence();
+}
+
+// spectrum bin held in slot s of frame_power_spectrum's p[]
+__device__ __forceinline__ int spec_bin(int s, int lane) {
+  if (s < 8) return lane + 64 * s;
+  if (lane == 0 && s == 8) return 512;
+  return 1024 - lane - 64 * (s - 8);
 }
 
 // critical-band grouping of a spectrum held in LDS (fftearmodel.c:604-620)
@@ -250,7 +288,7 @@ struct FrameSrc {
 };
 
 template <int NB>
-__global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
+__global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63;
   // 0 = reference wave, 1 = test wave; wave-uniform, so keep it (and all that hangs on it) scalar
@@ -349,12 +387,15 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
   // Both waves are in lock step here, the two barriers are cheap.
   int bw_ref = 0, bw_test = 0;
   {
-    double* xch = lds + 2 * kUnitDoubles;            // [2] exchanged scalars
+    // [2] exchanged scalars, at the end of the reference unit's scratch: that is beyond what the
+    // spreading phase uses and gets overwritten only after the next barrier but one
+    double* xch = lds + kOffScratch + 510;
     double thr = 0.;                                 // powers are >= 0
     if (sig == 1) {
-      // zero threshold = max over bins 921..1023 of the test spectrum
-      if (lane >= 25) thr = pspec[14];               // bin 896 + lane
-      thr = fmax(thr, pspec[15]);                    // bin 960 + lane
+      // zero threshold = max over bins 921..1023 of the test spectrum: the mirror bins 1024 - (lane + 64 q)
+      // of q = 0 (lanes 1..63) and q = 1 (lanes 0..39)
+      if (lane >= 1) thr = pspec[8];
+      if (lane <= 39) thr = fmax(thr, pspec[9]);
       thr = wave_max(thr);
       if (lane == 0) xch[0] = thr;
     }
@@ -362,9 +403,9 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     thr = xch[0];
     if (sig == 0) {
 #pragma unroll
-      for (int q = 0; q < 15; ++q) {                 // ascending bins: the last hit is the largest
-        const int k = lane + 64 * q;
-        if (k < 921 && pspec[q] > 10. * thr) bw_ref = k + 1;
+      for (int s = 0; s < 16; ++s) {
+        const int k = spec_bin(s, lane);
+        if (k < 921 && pspec[s] > 10. * thr) bw_ref = max(bw_ref, k + 1);
       }
       bw_ref = wave_max_i(bw_ref);
       if (lane == 0) xch[1] = (double)bw_ref;
@@ -373,9 +414,9 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     bw_ref = (int)xch[1];
     if (sig == 1 && bw_ref > 346) {
 #pragma unroll
-      for (int q = 0; q < 15; ++q) {
-        const int k = lane + 64 * q;
-        if (k < bw_ref && pspec[q] >= 3.16227766016838 * thr) bw_test = k + 1;
+      for (int s = 0; s < 16; ++s) {
+        const int k = spec_bin(s, lane);
+        if (k < bw_ref && pspec[s] >= 3.16227766016838 * thr) bw_test = max(bw_test, k + 1);
       }
       bw_test = wave_max_i(bw_test);
     }
@@ -405,13 +446,16 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
     const int b = b0 + s;
     if (b < NB) {
       const double pp = ppx[b] + bt->internal_noise[b];                                            // :483-485
-      // Kabal (23)-(24); fftearmodel.c:649-656.  a^y evaluated as exp(y ln a).
-      const double ln_a = bt->ln_aUC[b] + bt->dz02 * log_pos(pp);
-      const double a_uce = exp_fast(ln_a);
+      // Kabal (23)-(24); fftearmodel.c:649-656.  a^y evaluated as exp(y ln a); the three powers of
+      // aUCE share one exponential (t = aUCE^0.2: aUCE^0.4 = t^2, aUCE = t^5), and En^0.4 takes its
+      // logarithm as ln Pp - ln(gIL + gIU - 1) instead of dividing first
+      const double ln_pp = log_pos(pp);
+      const double ln_a = bt->ln_aUC[b] + bt->dz02 * ln_pp;
+      const double t = exp_fast(0.2 * ln_a), t2 = t * t;
+      const double a_uce = t2 * t2 * t;
       const double g_iu = div_fast(1. - exp_fast((double)(NB - b) * ln_a), 1. - a_uce);
-      const double en = div_fast(pp, bt->gIL[b] + g_iu - 1.);
-      ae[s] = exp_fast(0.4 * ln_a);
-      ene[s] = pow_pos(en, 0.4);
+      ae[s] = t2;
+      ene[s] = exp_fast(0.4 * (ln_pp - log_pos(bt->gIL[b] + g_iu - 1.)));
     } else {
       ae[s] = 0.;
       ene[s] = 0.;
@@ -469,49 +513,20 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
   __syncthreads();                                   // both spectra are in LDS
   const double* pw_ref = lds + kOffPw;
   double* pw_test = lds + kUnitDoubles + kOffPw;
-  double* dlog = lds + kOffScratch;                          // [512] shared: ln(Pw_test / Pw_ref)
-  double* cbuf = lds + kUnitDoubles + kOffScratch;           // [2][256] shared: correlation by lag, per k half
+  double* sa = lds + kOffScratch;                            // [512] the reference unit's scratch
+  double* sb = lds + kUnitDoubles + kOffScratch;             // [512] the test unit's scratch
 
-  // ---- error harmonic structure, part 1 (movs.c:1383-1391): both waves, 256 bins each ----
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k = 256 * sig + lane + 64 * j;
-    const double fr = pw_ref[k], ft = pw_test[k];
-    dlog[k] = (fr == 0. && ft == 0.) ? 0. : log_nonneg(ft / fr);   // +-inf when one side is digital silence
-  }
-  __syncthreads();
-  // ---- part 2: c[l] = sum_{k<256} d[k] d[k+l]  (the reference evaluates the same sums through
-  // 512-point FFTs, movs.c:1279-1315).  Each wave takes half of the k range for all 256 lags; a
-  // lane owns four consecutive lags and walks k in steps of four: a 4 x 4 register tile, 16 FMAs
-  // per two broadcast and two streaming 16-byte LDS reads.  The halves are added in part 3.
+  // ---- error harmonic structure, part 1 (movs.c:1383-1391): d[k] = ln(Pw_test / Pw_ref), k < 512.
+  // The test wave takes 6 of the 8 values per lane: its tail (noise spectrum) is the shorter one.
   {
-    const int l0 = 4 * lane;
-    const int k0 = 128 * sig;
-    double c[4] = {0., 0., 0., 0.};
-    double w[8];
-    {
-      const double2 a = *reinterpret_cast<const double2*>(dlog + k0 + l0);
-      const double2 b = *reinterpret_cast<const double2*>(dlog + k0 + l0 + 2);
-      w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
+    double* dlog = sa;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if (sig == 0 && j >= 2) break;
+      const int k = (sig == 0 ? 0 : 128) + lane + 64 * j;
+      const double fr = pw_ref[k], ft = pw_test[k];
+      dlog[k] = (fr == 0. && ft == 0.) ? 0. : log_nonneg(ft / fr);   // +-inf when one side is digital silence
     }
-#pragma unroll 4
-    for (int k = k0; k < k0 + 128; k += 4) {
-      const double2 d01 = *reinterpret_cast<const double2*>(dlog + k);        // broadcast
-      const double2 d23 = *reinterpret_cast<const double2*>(dlog + k + 2);
-      const double2 a = *reinterpret_cast<const double2*>(dlog + k + l0 + 4);
-      const double2 b = *reinterpret_cast<const double2*>(dlog + k + l0 + 6);  // [.. + 7] <= 511
-      w[4] = a.x; w[5] = a.y; w[6] = b.x; w[7] = b.y;
-      const double dk[4] = {d01.x, d01.y, d23.x, d23.y};
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c[j] = fma(dk[i], w[i + j], c[j]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w[i] = w[4 + i];
-    }
-    double2* out = reinterpret_cast<double2*>(cbuf + 256 * sig + l0);
-    out[0] = make_double2(c[0], c[1]);
-    out[1] = make_double2(c[2], c[3]);
   }
   __syncthreads();
 
@@ -535,93 +550,7 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
       rec[kRecBwRef] = (double)bw_ref;
       rec[kRecBwTest] = (double)bw_test;
     }
-  } else {
-    // ---- error harmonic structure, part 3 (movs.c:1393-1441): lane owns lags lane + 64 m ----
-    double* d = dlog;
-    double c[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) c[m] = cbuf[lane + 64 * m] + cbuf[256 + lane + 64 * m];
-    const double d0 = __shfl(c[0], 0, 64);
-    // running window energy dk[l] = d0 + sum_{j<l} (d[j+256]^2 - d[j]^2)   (:1413-1418)
-    {
-      double g[4], pre = 0.;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int j = 4 * lane + t;
-        const double hi = d[j + 256], lo = d[j];
-        g[t] = hi * hi - lo * lo;
-      }
-      const double tot = g[0] + g[1] + g[2] + g[3];
-      double inc = tot;                              // inclusive scan over lanes
-#pragma unroll
-      for (int dd = 1; dd < 64; dd <<= 1) {
-        const double o = __shfl_up(inc, dd, 64);
-        if (lane >= dd) inc += o;
-      }
-      pre = d0 + (inc - tot);
-      wave_lds_fence();
-      double run = pre;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        d[4 * lane + t] = run;                       // overwrites d[0..255] (all reads are done)
-        run += g[t];
-      }
-      wave_lds_fence();
-    }
-    double cavg = 0.;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      c[m] /= sqrt(d0 * d[lane + 64 * m]);
-      cavg += c[m];
-    }
-    cavg = wave_sum(cavg) / 256.;
-    // mean removed before windowing (EHS_SUBTRACT_DC_BEFORE_WINDOW 1), 256-point DFT
-    cplx u[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) u[m] = {(c[m] - cavg) * ct->ehs_window[lane + 64 * m], 0.};
-    wave_lds_fence();
-    double2* xb = reinterpret_cast<double2*>(scratch);   // 256 complex
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int p = 1 << (2 * pass);
-      const int k = lane & (p - 1);
-      if (pass > 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double2 v = xb[lane + 64 * r];
-          u[r] = {v.x, v.y};
-        }
-#pragma unroll
-        for (int r = 1; r < 4; ++r) {
-          const int t = r * k * (512 >> (2 * pass));   // W_{4p}^(r k) = W_2048^(r k 512/p)
-          u[r] = cmul(u[r], {ct->tw_re[t], ct->tw_im[t]});
-        }
-      }
-      dft4(u[0], u[1], u[2], u[3]);
-      if (pass < 3) {
-        const int j = (lane - k) * 4 + k;
-        wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xb[j + r * p] = make_double2(u[r].re, u[r].im);
-        wave_lds_fence();
-      }
-    }
-    // u[r] = C[lane + 64 r]; EHS = highest |C|^2 that exceeds its left neighbour, bins 1..128
-    const double s0 = u[0].re * u[0].re + u[0].im * u[0].im;
-    const double s1 = u[1].re * u[1].re + u[1].im * u[1].im;
-    const double s2 = u[2].re * u[2].re + u[2].im * u[2].im;
-    const double s0_up = __shfl_up(s0, 1, 64), s1_up = __shfl_up(s1, 1, 64);
-    const double s0_last = __shfl(s0, 63, 64), s1_last = __shfl(s1, 63, 64);
-    const double prev0 = s0_up;                           // valid for lane >= 1
-    const double prev1 = lane == 0 ? s0_last : s1_up;
-    double best = 0.;
-    if (lane >= 1 && s0 > prev0) best = s0;
-    if (s1 > prev1 && s1 > best) best = s1;
-    if (lane == 0 && s2 > s1_last && s2 > best) best = s2;
-    best = wave_max(best);
-    if (lane == 0) rec[kRecEhs] = best;
-    // ---- totalsnr energies over the hop (gstpeaq.c:913-918; float products).  Done by the
-    // reference wave: its tail (EHS part 3) is shorter than the test wave's (noise spectrum) --------
+    // ---- totalsnr energies over the hop (gstpeaq.c:913-918; float products) ------------------------
     double se = 0., ne = 0.;
     int lane_q = lane;                               // opaque copy, see above
     asm volatile("" : "+v"(lane_q));
@@ -648,13 +577,219 @@ __global__ __launch_bounds__(128, 3) void frontend_kernel(FrontendArgs a) {
       rec[kRecSigE] = se;
       rec[kRecNoiseE] = ne;
     }
+  } else {
+    // ---- error harmonic structure, part 2: c[l] = sum_{k<256} d[k] d[k+l], l < 256, the way the
+    // reference does it (movs.c:1279-1315): with A = DFT_512(d[0..255], zero padded) and
+    // B = DFT_512(d[0..511]) the sums are the inverse DFT of B conj(A).  Both transforms of real data
+    // come out of ONE complex 512-point FFT of a + i b (8 points per lane, radix 8 x 8 x 8, real and
+    // imaginary parts exchanged through the two scratch areas); the Hermitian product goes back
+    // through a 256-point complex FFT (the inverse real transform by the half-size trick).
+    cplx u[8];
+    double g[4], run_in;                             // window-energy increments of this lane's four lags
+    {
+      const double* d = sa;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const double v = d[lane + 64 * r];
+        u[r] = {r < 4 ? v : 0., v};
+      }
+      // running window energy dk[l] = d0 + sum_{j<l} (d[j+256]^2 - d[j]^2)   (:1413-1418); d0 = c[0]
+      // is added once it exists
+      double tot = 0.;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = 4 * lane + t;
+        const double hi = d[j + 256], lo = d[j];
+        g[t] = hi * hi - lo * lo;
+        tot += g[t];
+      }
+      double inc = tot;                              // inclusive scan over lanes
+#pragma unroll
+      for (int dd = 1; dd < 64; dd <<= 1) {
+        const double o = __shfl_up(inc, dd, 64);
+        if (lane >= dd) inc += o;
+      }
+      run_in = inc - tot;
+    }
+    wave_lds_fence();
+    // exchange steps of the 512-point Stockham FFT; the index swizzles keep the 8-byte stores of a
+    // 16-lane group on distinct banks (reads lane + 64 r are consecutive anyway)
+    auto exchange8 = [&](auto wr, auto swz) {
+      if (kEhsTwoBuffers) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int i = swz(wr(r));
+          sa[i] = u[r].re;
+          sb[i] = u[r].im;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int i = swz(lane + 64 * r);
+          u[r] = {sa[i], sb[i]};
+        }
+        wave_lds_fence();
+      } else {                                       // one 512-double buffer: real parts, then imaginary parts
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sa[swz(wr(r))] = u[r].re;
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) u[r].re = sa[swz(lane + 64 * r)];
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sa[swz(wr(r))] = u[r].im;
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) u[r].im = sa[swz(lane + 64 * r)];
+        wave_lds_fence();
+      }
+    };
+    auto twiddle8 = [&](int step) {                  // u[r] *= W_2048^(r step), r = 1..7
+      cplx w[8];
+      w[1] = {ct->tw_re[step], ct->tw_im[step]};
+      w[2] = {ct->tw_re[2 * step], ct->tw_im[2 * step]};
+      w[4] = {ct->tw_re[4 * step], ct->tw_im[4 * step]};
+      w[3] = cmul(w[1], w[2]);
+      w[5] = cmul(w[4], w[1]);
+      w[6] = cmul(w[4], w[2]);
+      w[7] = cmul(w[4], w[3]);
+#pragma unroll
+      for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], w[r]);
+    };
+    dft8(u);                                                         // sub-transform size 1 -> out[8 lane + r]
+    exchange8([&](int r) { return 8 * lane + r; }, [](int i) { return i ^ ((i >> 4) & 7); });
+    {
+      const int k = lane & 7;
+      twiddle8(32 * k);                                              // W_64^(r k)
+      dft8(u);                                                       // size 8 -> out[8 (lane - k) + k + 8 r]
+      const int j = (lane - k) * 8 + k;
+      exchange8([&](int r) { return j + 8 * r; }, [](int i) { return i ^ (((i >> 6) & 1) << 3); });
+    }
+    twiddle8(4 * lane);                                              // W_512^(r lane)
+    dft8(u);                                                         // u[r] = (A + i B)[lane + 64 r]
+    // Separate the two spectra and multiply, bins k = lane + 64 r < 256 (and 256 itself in lane 0);
+    // the mirror bin 512 - k sits in lane 64 - lane, slot 7 - r (lane 0: own slot 8 - r).
+    // 2A = Z[k] + conj Z[512-k], 2B = (Z[k] - conj Z[512-k]) / i, C = B conj(A); all factors of two
+    // (and the reference's 1/512) are applied at the very end.
+    const int partner = (64 - lane) & 63;
+    cplx cc[4];
+    double c256 = 0.;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      cplx zm = {__shfl(u[7 - r].re, partner, 64), __shfl(u[7 - r].im, partner, 64)};
+      if (lane == 0) zm = u[(8 - r) & 7];
+      const cplx a2 = {u[r].re + zm.re, u[r].im - zm.im};
+      const cplx b2 = {u[r].im + zm.im, zm.re - u[r].re};
+      cc[r] = {b2.re * a2.re + b2.im * a2.im, b2.im * a2.re - b2.re * a2.im};
+    }
+    if (lane == 0) c256 = (2. * u[4].re) * (2. * u[4].im);           // bin 256: A and B are real there
+    // Inverse real transform by the half-size trick: with E = C[k] + conj C[256-k],
+    // O = (C[k] - conj C[256-k]) W_512^-k the sequence Z[k] = E + i O (k < 256) is the DFT of
+    // c[2m] + i c[2m+1].  C[256-k]: lane 64 - lane, slot 3 - r (lane 0: own slot 4 - r, C[256] for r = 0).
+    // The inverse 256-point transform runs as a forward one on conj Z.
+    cplx v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      cplx cm = {__shfl(cc[3 - r].re, partner, 64), __shfl(cc[3 - r].im, partner, 64)};
+      if (lane == 0) cm = r == 0 ? cplx{c256, 0.} : cc[4 - r];
+      const int k = lane + 64 * r;
+      const cplx e = {cc[r].re + cm.re, cc[r].im - cm.im};
+      const cplx od = {cc[r].re - cm.re, cc[r].im + cm.im};
+      const cplx wk = {ct->tw_re[4 * k], -ct->tw_im[4 * k]};         // W_512^-k = conj W_2048^(4 k)
+      const cplx o = cmul(od, wk);
+      v[r] = {e.re - o.im, -(e.im + o.re)};                          // conj(E + i O)
+    }
+    wave_lds_fence();
+    double2* xb = reinterpret_cast<double2*>(sa);        // 256 complex
+    auto fft256 = [&](cplx (&w)[4]) {
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int p = 1 << (2 * pass);
+        const int k = lane & (p - 1);
+        if (pass > 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double2 x = xb[lane + 64 * r];
+            w[r] = {x.x, x.y};
+          }
+#pragma unroll
+          for (int r = 1; r < 4; ++r) {
+            const int t = r * k * (512 >> (2 * pass));   // W_{4p}^(r k) = W_2048^(r k 512/p)
+            w[r] = cmul(w[r], {ct->tw_re[t], ct->tw_im[t]});
+          }
+        }
+        dft4(w[0], w[1], w[2], w[3]);
+        if (pass < 3) {
+          const int j = (lane - k) * 4 + k;
+          wave_lds_fence();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xb[j + r * p] = make_double2(w[r].re, w[r].im);
+          wave_lds_fence();
+        }
+      }
+    };
+    fft256(v);
+    // v[r] = conj of (256 x) (c[2m] + i c[2m+1]), m = lane + 64 r; lags below 256 <=> r < 2.
+    // Scale: 1/4 (A, B) x 1/2 (E, O) x 1/256 (inverse transform) x ... the reference's 1/512 IS that
+    // transform's normalisation -> 1/2048 in all.
+    wave_lds_fence();
+    {
+      double2* cb = reinterpret_cast<double2*>(sb);      // c[l], l < 256, as 128 pairs
+      constexpr double kScale = 1. / 2048.;
+      cb[lane] = make_double2(v[0].re * kScale, -v[0].im * kScale);
+      cb[lane + 64] = make_double2(v[1].re * kScale, -v[1].im * kScale);
+    }
+    wave_lds_fence();
+    // ---- part 3 (movs.c:1393-1441): lane owns lags lane + 64 m ------------------------------------------
+    double* d = sa;
+    double c[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) c[m] = sb[lane + 64 * m];
+    const double d0 = __shfl(c[0], 0, 64);
+    {
+      wave_lds_fence();
+      double run = d0 + run_in;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        d[4 * lane + t] = run;                       // dk[l], l = 4 lane + t
+        run += g[t];
+      }
+      wave_lds_fence();
+    }
+    double cavg = 0.;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      c[m] *= rsqrt_pos(d0 * d[lane + 64 * m]);      // NaN when d0 = 0 (identical signals), as in the reference
+      cavg += c[m];
+    }
+    cavg = wave_sum(cavg) / 256.;
+    // mean removed before windowing (EHS_SUBTRACT_DC_BEFORE_WINDOW 1), 256-point DFT
+    cplx w4[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) w4[m] = {(c[m] - cavg) * ct->ehs_window[lane + 64 * m], 0.};
+    wave_lds_fence();
+    fft256(w4);
+    // w4[r] = C[lane + 64 r]; EHS = highest |C|^2 that exceeds its left neighbour, bins 1..128
+    const double s0 = w4[0].re * w4[0].re + w4[0].im * w4[0].im;
+    const double s1 = w4[1].re * w4[1].re + w4[1].im * w4[1].im;
+    const double s2 = w4[2].re * w4[2].re + w4[2].im * w4[2].im;
+    const double s0_up = __shfl_up(s0, 1, 64), s1_up = __shfl_up(s1, 1, 64);
+    const double s0_last = __shfl(s0, 63, 64), s1_last = __shfl(s1, 63, 64);
+    const double prev0 = s0_up;                           // valid for lane >= 1
+    const double prev1 = lane == 0 ? s0_last : s1_up;
+    double best = 0.;
+    if (lane >= 1 && s0 > prev0) best = s0;
+    if (s1 > prev1 && s1 > best) best = s1;
+    if (lane == 0 && s2 > s1_last && s2 > best) best = s2;
+    best = wave_max(best);
+    if (lane == 0) rec[kRecEhs] = best;
   }
 }
 
 hipError_t launch_frontend(int bands, const FrontendArgs& a, unsigned n_pairs, hipStream_t stream) {
   const unsigned grid = n_pairs * a.frames_per_launch * a.channels;
   if (grid == 0) return hipSuccess;
-  const size_t lds = (2 * kUnitDoubles + 2) * sizeof(double);
+  const size_t lds = kLdsDoubles * sizeof(double);
   if (bands == 109)
     hipLaunchKernelGGL(frontend_kernel<109>, dim3(grid), dim3(128), lds, stream, a);
   else if (bands == 55)

@@ -56,31 +56,100 @@ __device__ __forceinline__ void dft16(cplx (&x)[16]) {
     }
 }
 
-// ---- cross-lane reductions over the 64 lanes of a wave (result in every lane)
+// 8-point forward DFT in registers, natural order in and out
+__device__ __forceinline__ void dft8(cplx (&x)[8]) {
+  constexpr double c = 0.70710678118654752440;
+  cplx a0 = cadd(x[0], x[4]), a1 = cadd(x[1], x[5]), a2 = cadd(x[2], x[6]), a3 = cadd(x[3], x[7]);
+  cplx b0 = csub(x[0], x[4]), b1 = csub(x[1], x[5]), b2 = csub(x[2], x[6]), b3 = csub(x[3], x[7]);
+  b1 = {c * (b1.re + b1.im), c * (b1.im - b1.re)};      // * W8^1 = (1 - i) / sqrt 2
+  b2 = cmul_mi(b2);                                       // * W8^2 = -i
+  b3 = {c * (b3.im - b3.re), -c * (b3.re + b3.im)};      // * W8^3 = (-1 - i) / sqrt 2
+  dft4(a0, a1, a2, a3);
+  dft4(b0, b1, b2, b3);
+  x[0] = a0; x[2] = a1; x[4] = a2; x[6] = a3;
+  x[1] = b0; x[3] = b1; x[5] = b2; x[7] = b3;
+}
+
+// ---- cross-lane reductions over the 64 lanes of a wave (result in every lane) -----------------
+// Butterfly over the lane bits 1, 2, 4, 8 with DPP row operations (VALU, no LDS traffic) and over
+// 16 and 32 with gfx950's v_permlane16_swap / v_permlane32_swap.  The combining operation is
+// commutative, so every lane ends with the bit-identical result.  (The generic __shfl_xor lowers to
+// ds_bpermute_b32: two LDS-crossbar instructions and a round trip of ~50+ cycles per step and
+// double -- the reductions were a tenth of the front end's LDS instructions.)
+enum : int {
+  kDppXor1 = 0xB1,         // quad_perm [1,0,3,2]
+  kDppXor2 = 0x4E,         // quad_perm [2,3,0,1]
+  kDppHalfMirror = 0x141,  // lane i <- lane 7 - i of its group of 8 (all lanes of a quad agree by then)
+  kDppMirror = 0x140       // lane i <- lane 15 - i of its row of 16
+};
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  return __hiloint2double(dpp_i<CTRL>(__double2hiint(v)), dpp_i<CTRL>(__double2loint(v)));
+}
+// the values of lane ^ 16 (ROWS16) or lane ^ 32 as a pair {own half's copy, other half's}; which
+// is which depends on the lane, the (commutative) caller does not care
+template <bool ROWS16>
+__device__ __forceinline__ void swap_halves_i(int v, int& a, int& b) {
+  if (ROWS16) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    a = (int)r[0];
+    b = (int)r[1];
+  } else {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    a = (int)r[0];
+    b = (int)r[1];
+  }
+}
+template <bool ROWS16>
+__device__ __forceinline__ void swap_halves_d(double v, double& a, double& b) {
+  int alo, blo, ahi, bhi;
+  swap_halves_i<ROWS16>(__double2loint(v), alo, blo);
+  swap_halves_i<ROWS16>(__double2hiint(v), ahi, bhi);
+  a = __hiloint2double(ahi, alo);
+  b = __hiloint2double(bhi, blo);
+}
+template <typename OP>
+__device__ __forceinline__ double wave_reduce_d(double v, OP op) {
+  v = op(v, dpp_d<kDppXor1>(v));
+  v = op(v, dpp_d<kDppXor2>(v));
+  v = op(v, dpp_d<kDppHalfMirror>(v));
+  v = op(v, dpp_d<kDppMirror>(v));
+  double a, b;
+  swap_halves_d<true>(v, a, b);
+  v = op(a, b);
+  swap_halves_d<false>(v, a, b);
+  return op(a, b);
+}
+template <typename OP>
+__device__ __forceinline__ int wave_reduce_i(int v, OP op) {
+  v = op(v, dpp_i<kDppXor1>(v));
+  v = op(v, dpp_i<kDppXor2>(v));
+  v = op(v, dpp_i<kDppHalfMirror>(v));
+  v = op(v, dpp_i<kDppMirror>(v));
+  int a, b;
+  swap_halves_i<true>(v, a, b);
+  v = op(a, b);
+  swap_halves_i<false>(v, a, b);
+  return op(a, b);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+  return wave_reduce_d(v, [](double x, double y) { return x + y; });
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
-  return v;
+  return wave_reduce_d(v, [](double x, double y) { return fmax(x, y); });
 }
 __device__ __forceinline__ double wave_prod(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v *= __shfl_xor(v, d, 64);
-  return v;
+  return wave_reduce_d(v, [](double x, double y) { return x * y; });
 }
 __device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-  return v;
+  return wave_reduce_i(v, [](int x, int y) { return max(x, y); });
 }
 __device__ __forceinline__ int wave_or_i(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d, 64);
-  return v;
+  return wave_reduce_i(v, [](int x, int y) { return x | y; });
 }
 
 // ---- logarithm and exponential for this model ------------------------------------------
@@ -176,6 +245,15 @@ __device__ __forceinline__ double sqrt_pos(double x) {
   h = fma(h, r, h);
   g = fma(fma(-g, g, x), h, g);
   return x == 0. ? 0. : g;
+}
+
+// 1 / sqrt(x) for finite x > 0, <= 1 ulp or so; x = 0 gives NaN (inf * 0 in the Newton step), x < 0 NaN
+__device__ __forceinline__ double rsqrt_pos(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * r, r, 1.);                     // 1 - x r^2
+  r = fma(r * e, fma(e, 0.375, 0.5), r);             // r (1 + e/2 + 3 e^2 / 8)
+  e = fma(-x * r, r, 1.);
+  return fma(r * e, 0.5, r);
 }
 
 constexpr double kInvLn10 = 0.43429448190325182765;   // log10 x = ln x / ln 10

@@ -127,7 +127,7 @@ main (int argc, char **argv)
         clock_gettime (CLOCK_REALTIME, &a);
       while (a.tv_sec + 1e-9 * a.tv_nsec < start_epoch);
       t_begin = a.tv_sec + 1e-9 * a.tv_nsec;
-      for (rep = 0; rep < repeats; rep++)
+      for (rep = 0; repeats > 0 ? rep < repeats : rep == 0 || (clock_gettime (CLOCK_REALTIME, &b), b.tv_sec + 1e-9 * b.tv_nsec < t_begin - repeats); rep++)
         for (p = 0; p < np; p++) {
           double m[11], d, o;
           orc_session *s = orc_session_new (adv, ch, 92.);

@@ -157,10 +157,10 @@ epoch_s (void)
  * the inputs is not timed, pipeline construction/teardown is (a few ms).
  * repeats == 0: NPAIRS distinct pairs, each generated and then timed on its own
  *   (sum of the per-pair times).
- * repeats  > 0: NPAIRS distinct pairs are generated first, then -- from the wall
+ * repeats != 0: NPAIRS distinct pairs are generated first, then -- from the wall
  *   clock instant start_epoch on, so that many such processes (one per core) run
- *   their timed regions together -- the set is processed `repeats` times in one
- *   timed region.  The JSON carries the region's begin/end on the CLOCK_REALTIME
+ *   their timed regions together -- the set is processed `repeats` times (repeats < 0:
+ *   over and over for -repeats seconds) in one timed region.  The JSON carries the region's begin/end on the CLOCK_REALTIME
  *   axis for the parent to aggregate.
  * Either way the MOVs / DI / ODG of the first pass over each pair are printed. */
 static int
@@ -199,7 +199,8 @@ time_pairs (int advanced, int channels, uint32_t seed0, int n_pairs, uint32_t ns
     while (epoch_s () < start_epoch)
       usleep (200);
     t_begin = epoch_s ();
-    for (rep = 0; rep < repeats; rep++)
+    /* repeats < 0: as many passes as fit into -repeats seconds (bounded run time on any host) */
+    for (rep = 0; repeats > 0 ? rep < repeats : (rep == 0 || epoch_s () < t_begin - repeats); rep++)
       for (p = 0; p < n_pairs; p++) {
         double m[COUNT_MOV_BASIC], d, o;
         unsigned fc;

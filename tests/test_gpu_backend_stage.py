@@ -97,12 +97,13 @@ def test_backend_patterns_match_oracle_per_frame(gpu, case):
     import gstpeaq_amd
     import gstpeaq_amd.capi as capi
     ref, test = case_defs.make_inputs(case)
-    n_frames = (len(ref) - 2048) // 1024 + 1
+    n_frames = (len(ref) - 2048) // 1024 + 2           # all full frames + the zero-padded flush frame
     recs = gstpeaq_amd.debug_frontend(gpu.ctx(), NB, torch.from_numpy(ref).cuda(), torch.from_numpy(test).cuda(),
                                       n_frames)
     d, res = capi.debug_backend(gpu.ctx(), recs)
-    o_ref = orc.fftear(NB, ref[:, 0], n_frames, 1024)
-    o_test = orc.fftear(NB, test[:, 0], n_frames, 1024)
+    pad = np.zeros(2048, dtype=np.float32)             # do_flush pads with zeros (gstpeaq.c:733-738)
+    o_ref = orc.fftear(NB, np.concatenate([ref[:, 0], pad]), n_frames, 1024)
+    o_test = orc.fftear(NB, np.concatenate([test[:, 0], pad]), n_frames, 1024)
     np.testing.assert_allclose(d["exc_ref"][:, 0], o_ref["excitation"], rtol=1e-9)
     np.testing.assert_allclose(d["exc_test"][:, 0], o_test["excitation"], rtol=1e-9)
     ad_r, ad_t = orc.leveladapt(NB, o_ref["excitation"], o_test["excitation"])
@@ -117,8 +118,8 @@ def test_backend_patterns_match_oracle_per_frame(gpu, case):
     upto = (gate[0] + 1) if gate.size else n_frames
     np.testing.assert_allclose(d["loudness"][:upto, 0, 0], o_ref["loudness"][:upto], rtol=1e-9)
     np.testing.assert_allclose(d["loudness"][:upto, 0, 1], o_test["loudness"][:upto], rtol=1e-9)
-    # and the MOVs of the frames fed equal a whole-pair run truncated to the same frames
-    exp = orc.run_pair(0, ref[: (n_frames - 1) * 1024 + 2048], test[: (n_frames - 1) * 1024 + 2048])
+    # and the MOVs after the last frame are those of the whole pair
+    exp = orc.run_pair(0, ref, test)
     assert res["frames"] == exp["frames"] == n_frames
     np.testing.assert_allclose(res["movs"], exp["movs"], rtol=1e-7, atol=1e-9)
     assert abs(res["odg"] - exp["odg"]) < 1e-6
