@@ -125,6 +125,7 @@ struct peaq_ctx {
   std::vector<TimedSpan> spans;
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
+  unsigned long long* d_prof = nullptr;   // -DPEAQ_FE_PROFILE builds only
 
   hipEvent_t next_event() {
     if (events_used == event_pool.size()) {
@@ -181,6 +182,10 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->aux3, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->aux4, hipStreamNonBlocking));
+#ifdef PEAQ_FE_PROFILE
+  HIP_TRY(hipMalloc(&c->d_prof, 64 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(c->d_prof, 0, 64 * sizeof(unsigned long long)));
+#endif
     return PEAQ_OK;
   }();
   if (rc != PEAQ_OK) {           // nothing allocated so far is leaked (destroy copes with a half-built context)
@@ -201,6 +206,7 @@ extern "C" void peaq_ctx_destroy(peaq_ctx* c) {
   (void)hipFree(c->d_bands55);
   (void)hipFree(c->d_bands40);
   (void)hipFree(c->d_fb);
+  (void)hipFree(c->d_prof);
   c->records.release();
   c->records2.release();
   if (c->aux) (void)hipStreamDestroy(c->aux);
@@ -221,6 +227,18 @@ extern "C" void peaq_ctx_destroy(peaq_ctx* c) {
 }
 
 extern "C" int peaq_ctx_device(const peaq_ctx* c) { return c ? c->device : -1; }
+
+#ifdef PEAQ_FE_PROFILE
+// development builds only: reads and clears the front end's phase counters (tools/fe_profile.py)
+extern "C" int peaq_debug_frontend_profile(peaq_ctx* c, unsigned long long* out64) {
+  if (!c || !out64) return fail(PEAQ_ERR_ARG, "peaq_debug_frontend_profile: NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out64, c->d_prof, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(c->d_prof, 0, 64 * sizeof(unsigned long long)));
+  return PEAQ_OK;
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // batch
@@ -474,6 +492,7 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
   fa.level_factor = fft_level_factor(level_db);
   fa.common = c->d_common;
   fa.bands = advanced ? c->d_bands55 : c->d_bands109;    // gstpeaq.c:521-526
+  fa.prof = c->d_prof;
   BackendArgs ba{};
   ba.n_frames = d_nframes;
   ba.n_frames_uniform = max_frames;

@@ -33,7 +33,10 @@ constexpr int kMfTotalSteps = 261;
 
 // ---- constant tables (built on the host in FP64, peaq_tables.cpp) ----------
 struct CommonTables {
-  double hann[kFrame];          // fftearmodel.c:167-172
+  // Hann window, fftearmodel.c:167-172, in the form the front end evaluates it: sample k = 2 (lane + 64 r) + j sits at the
+  // angle theta(2 lane + j) + r * 2 pi 128 / 2047, so w = A - A cos(theta_lane) C_r + A sin(theta_lane) S_r
+  // with A = sqrt(8/3) / 2 and 16 compile-time (C_r, S_r): 2 KB of table per wave instead of 16 KB
+  double hann_lane[64][4];      // { A cos th(2l), A sin th(2l), A cos th(2l+1), A sin th(2l+1) }
   double ear_w2[kBins];         // fftearmodel.c:253-256
   double tw_re[kFrame];         // exp(-2 pi i k / 2048), k = 0..2047
   double tw_im[kFrame];

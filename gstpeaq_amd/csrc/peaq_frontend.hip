@@ -192,12 +192,21 @@ __device__ __forceinline__ int spec_bin(int s, int lane) {
   return 1024 - lane - 64 * (s - 8);
 }
 
-// critical-band grouping of a spectrum held in LDS (fftearmodel.c:604-620)
+// critical-band grouping of a spectrum held in LDS (fftearmodel.c:604-620).  The interior bins are
+// fetched eight at a time (guarded: beyond the band the lane re-reads its first bin and adds zero),
+// so that a band of 25 bins costs four LDS round trips instead of 25; the order of the additions is
+// that of the plain loop.
 template <typename F>
 __device__ __forceinline__ double group_band(const BandTables* __restrict__ bt, int b, F spec) {
   const int lo = bt->lo[b], hi = bt->hi[b];
   double p = bt->wlo[b] * spec(lo) + bt->whi[b] * spec(hi);
-  for (int k = lo + 1; k < hi; ++k) p += spec(k);
+  for (int k0 = lo + 1; k0 < hi; k0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = spec(k0 + j < hi ? k0 + j : lo);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p += k0 + j < hi ? v[j] : 0.;
+  }
   return p < 1e-12 ? 1e-12 : p;
 }
 
@@ -230,7 +239,7 @@ __device__ __forceinline__ int boundary_detect(const float* ax, int n, int lane)
       }
     }
   }
-  return __shfl(res, 0, 64);
+  return __builtin_amdgcn_readfirstlane(res);
 }
 
 // XCD-aware bijective remap (the dispatcher places block b on XCD b % 8): work
@@ -260,7 +269,26 @@ struct FrameSrc {
   // samples 2n and 2n+1 of the frame; WHOLE: all 2048 samples exist and the start is aligned
   template <bool WHOLE>
   __device__ __forceinline__ void load2(int n, float& x0, float& x1) const {
+#ifdef PEAQ_FE_NOLOAD                                // experiment: how much of the kernel is load latency
+    x0 = (float)n * 1e-4f + (float)chan;
+    x1 = (float)left * 1e-6f - x0;
+    return;
+#endif
     if (WHOLE) {
+#ifdef PEAQ_FE_BUFLOAD
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000);
+      if (channels == 1) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, n * 8, 0, 0);
+        x0 = __uint_as_float(v.x);
+        x1 = __uint_as_float(v.y);
+      } else {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, n * 16, 0, 0);
+        x0 = __uint_as_float(chan ? v.y : v.x);
+        x1 = __uint_as_float(chan ? v.w : v.z);
+      }
+#else
       if (channels == 1) {
         const float2 v = reinterpret_cast<const float2*>(p)[n];
         x0 = v.x;
@@ -270,6 +298,7 @@ struct FrameSrc {
         x0 = chan ? v.y : v.x;
         x1 = chan ? v.w : v.z;
       }
+#endif
     } else {                                         // zero-padded flush frame (gstpeaq.c:733-738)
       const int i0 = 2 * n, i1 = i0 + 1;
       x0 = i0 < left ? p[i0 * channels + chan] : 0.f;
@@ -287,12 +316,29 @@ struct FrameSrc {
   }
 };
 
+// Phase timing for tools/fe_profile.py (development builds with -DPEAQ_FE_PROFILE only): the cycles
+// between consecutive marks are summed per wave role and phase.
+#ifdef PEAQ_FE_PROFILE
+#define FE_MARK(i)                                                                     \
+  do {                                                                                 \
+    const unsigned long long now_ = __builtin_readcyclecounter();                      \
+    if (a.prof && lane == 0 && (blockIdx.x & 127) == 5) atomicAdd(a.prof + sig * 16 + (i), now_ - prof_t_); \
+    prof_t_ = __builtin_readcyclecounter();                                            \
+  } while (0)
+#else
+#define FE_MARK(i) do { } while (0)
+#endif
+
 template <int NB>
 __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63;
   // 0 = reference wave, 1 = test wave; wave-uniform, so keep it (and all that hangs on it) scalar
   const int sig = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef PEAQ_FE_PROFILE
+  unsigned long long prof_t_ = __builtin_readcyclecounter();
+  if (a.prof && lane == 0 && (blockIdx.x & 127) == 5) atomicAdd(a.prof + 32 + sig, 1ull);   // one workgroup in 128 is sampled
+#endif
   double* unit = lds + sig * kUnitDoubles;
   double* scratch = unit + kOffScratch;
   const CommonTables* __restrict__ ct = a.common;
@@ -319,38 +365,84 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
   const size_t pair_off = (size_t)pair * a.pair_stride * a.channels;
   FrameSrc src_ref, src_test;
   {
+#ifdef PEAQ_FE_SAMEFRAME                             // experiment: every workgroup reads the same (cache-resident) frame
+    const long long s0 = 0;
+    src_ref.set(a.ref, s0 + a.off_ref, (long long)n_ref, a.channels, chan);
+    src_test.set(a.test, s0 + a.off_test, (long long)n_test, a.channels, chan);
+    if (false)
+#else
     const long long s0 = (long long)(frame - frame_origin) * kHop;
+#endif
+    {
     src_ref.set(a.ref + pair_off, s0 + a.off_ref, (long long)n_ref, a.channels, chan);
     src_test.set(a.test + pair_off, s0 + a.off_test, (long long)n_test, a.channels, chan);
+    }
   }
   const FrameSrc& src = sig ? src_test : src_ref;
   double* __restrict__ rec =
       a.records + ((size_t)(pair * a.frames_per_launch + fl) * a.channels + chan) * kRecDoubles;
 
-  // ---- load + window (fftearmodel.c:451-452), energy flag (:508-514) ----------
+  // ---- load + window (fftearmodel.c:451-452), energy flag (:508-514), totalsnr energies over the hop
+  // (gstpeaq.c:913-918; float products): the reference wave sums ref^2 from its own samples, the test
+  // wave fetches the reference's first 1024 samples in the same batch of loads for (ref - test)^2.
+  // The window is evaluated, not read: sample k = 2 (lane + 64 r) + j has the angle
+  // theta(2 lane + j) + r d, d = 2 pi 128 / 2047, so w = A (1 - cos) = A - (A cos th) C_r + (A sin th) S_r
+  // from four per-lane values and 32 literals -- 2 KB instead of 16 KB through the vector memory
+  // pipe per wave, which is what the first phase of this kernel waits for.
+  constexpr double kHannA = 0.81649658092772603273;             // sqrt(8/3) / 2
+  constexpr double kHannC[16] = {1.0, 0.923806101034885660186, 0.7068354246185547448714, 0.3821516543455241229047,
+                                 -0.0007673650086148258012924, -0.3835694472988822502431, -0.7079202261619581075015,
+                                 -0.9243926006499437062869, -0.9999988223018871071366, -0.9232174254904238786877,
+                                 -0.7057489581976599840459, -0.3807329612736016723471, 0.002302093218395832312485,
+                                 0.3849863367942118830771, 0.7090033602727326108775, 0.9249769229541590372578};
+  constexpr double kHannS[16] = {0.0, 0.382860663545790020567, 0.7073780336597309217442, 0.92409962292005024589,
+                                 0.99999970557542843387, 0.923512035167290059731, 0.7062923993579444458354,
+                                 0.3814424201155840173045, -0.001534729565367423810065, -0.3842780051874341062575,
+                                 -0.7084620018059667117941, -0.924685034052046356158, -0.9999973501798961346679,
+                                 -0.9229222721777677728372, -0.705205101457706221079, -0.3800232782373413192215};
+  const double2 hl0 = *reinterpret_cast<const double2*>(&ct->hann_lane[lane][0]);
+  const double2 hl1 = *reinterpret_cast<const double2*>(&ct->hann_lane[lane][2]);
   cplx z[16];
   float amax = 0.f;
-  double energy = 0.;
+  double energy = 0., hop = 0.;                      // hop: sum ref^2 (reference wave) / sum (ref - test)^2 (test wave)
   auto load_frame = [&](auto whole) {
+    constexpr bool W = decltype(whole)::value;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = lane + 64 * r;
       float x0, x1;
-      src.template load2<decltype(whole)::value>(n, x0, x1);
-      z[r] = {ct->hann[2 * n] * (double)x0, ct->hann[2 * n + 1] * (double)x1};
+      src.template load2<W>(n, x0, x1);
+      const double w0 = fma(hl0.y, kHannS[r], fma(-hl0.x, kHannC[r], kHannA));
+      const double w1 = fma(hl1.y, kHannS[r], fma(-hl1.x, kHannC[r], kHannA));
+      z[r] = {w0 * (double)x0, w1 * (double)x1};
       if (r >= 8) {                                  // samples 1024..2047; float products, double sum
         energy += (double)(x0 * x0);
         energy += (double)(x1 * x1);
+      } else if (sig == 0) {
+        hop += (double)(x0 * x0);
+        hop += (double)(x1 * x1);
+      } else {
+        float r0, r1;
+        src_ref.template load2<W>(n, r0, r1);
+        hop += (double)((r0 - x0) * (r0 - x0));
+        hop += (double)((r1 - x1) * (r1 - x1));
       }
       // a single sample above the threshold settles the boundary detector; sample 0
       // is excluded because the first tested window is [1..5]
       amax = fmaxf(amax, n == 0 ? fabsf(x1) : fmaxf(fabsf(x0), fabsf(x1)));
     }
   };
-  if (src.whole)                                     // one uniform branch, not one per sample
+  FE_MARK(13);                                       // work-item decoding, pointers
+  if (src.whole && (sig == 0 || src_ref.whole))      // one uniform branch, not one per sample
     load_frame(std::true_type{});
   else
     load_frame(std::false_type{});
+#ifdef PEAQ_FE_PROFILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  FE_MARK(14);                                       // sample loads + window
+  hop = wave_sum(hop);
+  if (lane == 0) rec[sig ? kRecNoiseE : kRecSigE] = hop;
   energy = wave_sum(energy);
   const int energy_flag = energy >= 8000. / (32768. * 32768.);
 
@@ -380,9 +472,11 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
   if (lane == 0)                                     // out now: nothing of this stays live over the transform
     rec[sig ? kRecFlagsTest : kRecFlagsRef] = (double)(above | (energy_flag << 1));
 
+  FE_MARK(0);                                        // load, window, flags
   double pspec[16];                                  // unweighted power spectrum, bin lane + 64 q
   frame_power_spectrum(z, pspec, unit, lane, ct, a.level_factor);
 
+  FE_MARK(1);                                        // FFT + split
   // ---- bandwidths (movs.c:776-809) on the unweighted spectra, straight from the registers.
   // Both waves are in lock step here, the two barriers are cheap.
   int bw_ref = 0, bw_test = 0;
@@ -422,6 +516,7 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
     }
   }
 
+  FE_MARK(2);                                        // bandwidths (two barriers)
   // ---- critical bands, internal noise, spreading ------------------------------------
   // lane owns bands 2*lane and 2*lane+1
   const double* pw = unit + kOffPw;
@@ -439,6 +534,7 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
     if (b2 != b1) ppx[b2] = group_band(bt, b2, [&](int k) { return pw[k]; });
   }
   wave_lds_fence();
+  FE_MARK(3);                                        // band grouping
   double ene[2], ae[2];
   const int b0 = 2 * lane;
 #pragma unroll
@@ -462,6 +558,7 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
     }
   }
   wave_lds_fence();
+  FE_MARK(4);                                        // logarithms / exponentials per band
   // upward spreading, Kabal (27): E2[j] += Ene[i] * aUCEe[i]^(j-i) for j > i.
   // The lane's two bands 2 lane and 2 lane + 1 reach target 2 lane + s after s and s - 1 steps:
   // their contributions are added in registers and leave as ONE LDS atomic per step; the
@@ -476,21 +573,15 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
       atomicAdd(&e2up[128 * (s & 1) + lane + (s >> 1)], r0 + r1);
     }
   }
+  FE_MARK(5);                                        // upward spreading loop
   // downward spreading, Kabal (28): E2[i-1] = aLe E2[i] + Ene[i-1]  (suffix scan)
   double dn0, dn1;
   {
     const double al = bt->aLe;
-    double v = ene[0] + al * ene[1];                 // pair-local
-    double m = al * al;                              // ratio per lane step
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const double o = __shfl_down(v, d, 64);
-      if (lane + d < 64) v += m * o;
-      m *= m;
-    }
-    const double nxt = __shfl_down(v, 1, 64);        // E2down[2 lane + 2]
+    const double v = wave_suffix_geometric(ene[0] + al * ene[1], al * al, lane);   // pair-local, then over the lanes
+    const double nxt = lane_above(v);                // E2down[2 lane + 2]; 0 beyond the last lane
     dn0 = v;
-    dn1 = ene[1] + (lane < 63 ? al * nxt : 0.);
+    dn1 = ene[1] + al * nxt;
   }
   wave_lds_fence();
   double unsm[2], loud[2];
@@ -510,7 +601,9 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
     *reinterpret_cast<double2*>(rec + (sig ? kRecLoudTest : kRecLoudRef) + b0) = make_double2(loud[0], loud[1]);
   }
 
+  FE_MARK(6);                                        // downward spreading, excitation, record
   __syncthreads();                                   // both spectra are in LDS
+  FE_MARK(7);                                        // barrier
   const double* pw_ref = lds + kOffPw;
   double* pw_test = lds + kUnitDoubles + kOffPw;
   double* sa = lds + kOffScratch;                            // [512] the reference unit's scratch
@@ -528,15 +621,27 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
       dlog[k] = (fr == 0. && ft == 0.) ? 0. : log_nonneg(ft / fr);   // +-inf when one side is digital silence
     }
   }
+  FE_MARK(8);                                        // log ratios
   __syncthreads();
+  FE_MARK(9);                                        // barrier
 
   if (sig == 1) {
     // ---- noise spectrum for the NMR MOVs (movs.c:992-996): one bin per lane and step, in place
     // over this unit's weighted spectrum (nobody reads it any more); then the band grouping ------
     wave_lds_fence();
-    for (int k = lane; k < kPwLen; k += 64) {
-      const double r = pw_ref[k], t = pw_test[k];
-      pw_test[k] = r - 2 * sqrt_pos(r * t) + t;
+    {
+      constexpr int kSteps = (kPwLen + 63) / 64;     // all loads first, then the arithmetic, then the stores
+      double r[kSteps], t[kSteps];
+#pragma unroll
+      for (int i = 0; i < kSteps; ++i) {
+        const int k = lane + 64 * i < kPwLen ? lane + 64 * i : 0;
+        r[i] = pw_ref[k];
+        t[i] = pw_test[k];
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int i = 0; i < kSteps; ++i)
+        if (lane + 64 * i < kPwLen) pw_test[lane + 64 * i] = r[i] - 2 * sqrt_pos(r[i] * t[i]) + t[i];
     }
     wave_lds_fence();
     if (lane < (NB + 1) / 2) {                        // balanced assignment as above, straight to the record
@@ -550,33 +655,7 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
       rec[kRecBwRef] = (double)bw_ref;
       rec[kRecBwTest] = (double)bw_test;
     }
-    // ---- totalsnr energies over the hop (gstpeaq.c:913-918; float products) ------------------------
-    double se = 0., ne = 0.;
-    int lane_q = lane;                               // opaque copy, see above
-    asm volatile("" : "+v"(lane_q));
-    auto hop_energy = [&](auto whole) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int n = lane_q + 64 * r;
-        float r0, r1, t0, t1;
-        src_ref.template load2<decltype(whole)::value>(n, r0, r1);
-        src_test.template load2<decltype(whole)::value>(n, t0, t1);
-        se += (double)(r0 * r0);
-        se += (double)(r1 * r1);
-        ne += (double)((r0 - t0) * (r0 - t0));
-        ne += (double)((r1 - t1) * (r1 - t1));
-      }
-    };
-    if (src_ref.whole && src_test.whole)
-      hop_energy(std::true_type{});
-    else
-      hop_energy(std::false_type{});
-    se = wave_sum(se);
-    ne = wave_sum(ne);
-    if (lane == 0) {
-      rec[kRecSigE] = se;
-      rec[kRecNoiseE] = ne;
-    }
+    FE_MARK(10);                                     // test wave: noise spectrum + grouping
   } else {
     // ---- error harmonic structure, part 2: c[l] = sum_{k<256} d[k] d[k+l], l < 256, the way the
     // reference does it (movs.c:1279-1315): with A = DFT_512(d[0..255], zero padded) and
@@ -603,13 +682,7 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
         g[t] = hi * hi - lo * lo;
         tot += g[t];
       }
-      double inc = tot;                              // inclusive scan over lanes
-#pragma unroll
-      for (int dd = 1; dd < 64; dd <<= 1) {
-        const double o = __shfl_up(inc, dd, 64);
-        if (lane >= dd) inc += o;
-      }
-      run_in = inc - tot;
+      run_in = wave_prefix_sum(tot, lane) - tot;     // exclusive scan over the lanes
     }
     wave_lds_fence();
     // exchange steps of the 512-point Stockham FFT; the index swizzles keep the 8-byte stores of a
@@ -667,6 +740,7 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
     }
     twiddle8(4 * lane);                                              // W_512^(r lane)
     dft8(u);                                                         // u[r] = (A + i B)[lane + 64 r]
+    FE_MARK(10);                                     // reference wave: 512-point FFT
     // Separate the two spectra and multiply, bins k = lane + 64 r < 256 (and 256 itself in lane 0);
     // the mirror bin 512 - k sits in lane 64 - lane, slot 7 - r (lane 0: own slot 8 - r).
     // 2A = Z[k] + conj Z[512-k], 2B = (Z[k] - conj Z[512-k]) / i, C = B conj(A); all factors of two
@@ -740,12 +814,13 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
       cb[lane + 64] = make_double2(v[1].re * kScale, -v[1].im * kScale);
     }
     wave_lds_fence();
+    FE_MARK(11);                                     // reference wave: product + inverse transform
     // ---- part 3 (movs.c:1393-1441): lane owns lags lane + 64 m ------------------------------------------
     double* d = sa;
     double c[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) c[m] = sb[lane + 64 * m];
-    const double d0 = __shfl(c[0], 0, 64);
+    const double d0 = read_lane<0>(c[0]);
     {
       wave_lds_fence();
       double run = d0 + run_in;
@@ -773,8 +848,8 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
     const double s0 = w4[0].re * w4[0].re + w4[0].im * w4[0].im;
     const double s1 = w4[1].re * w4[1].re + w4[1].im * w4[1].im;
     const double s2 = w4[2].re * w4[2].re + w4[2].im * w4[2].im;
-    const double s0_up = __shfl_up(s0, 1, 64), s1_up = __shfl_up(s1, 1, 64);
-    const double s0_last = __shfl(s0, 63, 64), s1_last = __shfl(s1, 63, 64);
+    const double s0_up = lane_below(s0), s1_up = lane_below(s1);
+    const double s0_last = read_lane<63>(s0), s1_last = read_lane<63>(s1);
     const double prev0 = s0_up;                           // valid for lane >= 1
     const double prev1 = lane == 0 ? s0_last : s1_up;
     double best = 0.;
@@ -783,6 +858,7 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
     if (lane == 0 && s2 > s1_last && s2 > best) best = s2;
     best = wave_max(best);
     if (lane == 0) rec[kRecEhs] = best;
+    FE_MARK(12);                                     // reference wave: normalise, window, 256-point FFT, peak
   }
 }
 

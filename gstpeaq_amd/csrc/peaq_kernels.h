@@ -34,6 +34,8 @@ struct FrontendArgs {
   // [pair_frame0[p], pair_frame0[p] + pair_nframes[p]) and its buffer starts at that frame.
   const uint32_t* pair_frame0;
   const uint32_t* pair_nframes;
+  // -DPEAQ_FE_PROFILE builds only (tools/fe_profile.py): [2 waves][16 phases] cycle sums + [32] wave count
+  unsigned long long* prof;
 };
 hipError_t launch_frontend(int bands, const FrontendArgs& a, unsigned n_pairs, hipStream_t stream);
 

@@ -203,8 +203,13 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
 
 void build_common_tables(CommonTables& c) {
   const int n = kFrame;
+  for (int l = 0; l < 64; ++l)
+    for (int j = 0; j < 2; ++j) {
+      const double th = 2 * kPi * (2 * l + j) / (n - 1), amp = std::sqrt(8.0 / 3.0) * 0.5;
+      c.hann_lane[l][2 * j] = amp * std::cos(th);
+      c.hann_lane[l][2 * j + 1] = amp * std::sin(th);
+    }
   for (int k = 0; k < n; ++k) {
-    c.hann[k] = std::sqrt(8.0 / 3.0) * 0.5 * (1.0 - std::cos(2 * kPi * k / (n - 1)));
     c.tw_re[k] = std::cos(2 * kPi * k / n);
     c.tw_im[k] = -std::sin(2 * kPi * k / n);
   }

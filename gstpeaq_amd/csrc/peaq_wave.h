@@ -112,6 +112,59 @@ __device__ __forceinline__ void swap_halves_d(double v, double& a, double& b) {
   a = __hiloint2double(ahi, alo);
   b = __hiloint2double(bhi, blo);
 }
+// ---- neighbours, broadcasts and scans without the LDS crossbar -----------------------------------
+// DPP shifts: row_shr:n / row_shl:n move data by n lanes inside a row of 16 (lane i reads lane i - n /
+// i + n), wave_shr:1 / wave_shl:1 by one lane across the whole wave; lanes without a source read 0.
+template <int CTRL>
+__device__ __forceinline__ double dpp_d0(double v) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int kDppRowShl = 0x100, kDppRowShr = 0x110, kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;
+__device__ __forceinline__ double lane_below(double v) { return dpp_d0<kDppWaveShr1>(v); }   // lane i <- lane i - 1
+__device__ __forceinline__ double lane_above(double v) { return dpp_d0<kDppWaveShl1>(v); }   // lane i <- lane i + 1
+// the value of lane l (a constant) in every lane, through the scalar registers
+template <int L>
+__device__ __forceinline__ double read_lane(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), L), __builtin_amdgcn_readlane(__double2loint(v), L));
+}
+// inclusive prefix sum over the lanes: lane i gets v_0 + ... + v_i
+__device__ __forceinline__ double wave_prefix_sum(double v, int lane) {
+  v += dpp_d0<kDppRowShr + 1>(v);
+  v += dpp_d0<kDppRowShr + 2>(v);
+  v += dpp_d0<kDppRowShr + 4>(v);
+  v += dpp_d0<kDppRowShr + 8>(v);
+  const double r0 = read_lane<15>(v), r1 = read_lane<31>(v), r2 = read_lane<47>(v);   // row totals
+  const double o2 = r0 + r1, o3 = o2 + r2;
+  const int row = lane >> 4;
+  return v + (row == 0 ? 0. : row == 1 ? r0 : row == 2 ? o2 : o3);
+}
+// weighted suffix sum: lane i gets sum_{j >= i} m^(j - i) v_j (m wave-uniform)
+__device__ __forceinline__ double wave_suffix_geometric(double v, double m, int lane) {
+  // m^(16 - (lane & 15)): the weight of the next row's total as seen from this lane
+  double wl = 1., base = m;
+  const int k = 16 - (lane & 15);
+#pragma unroll
+  for (int bit = 0; bit < 5; ++bit) {
+    wl = (k >> bit) & 1 ? wl * base : wl;
+    base *= base;
+  }
+  const double m16 = read_lane<0>(wl);               // lane 0: k = 16
+  v = fma(m, dpp_d0<kDppRowShl + 1>(v), v);
+  m *= m;
+  v = fma(m, dpp_d0<kDppRowShl + 2>(v), v);
+  m *= m;
+  v = fma(m, dpp_d0<kDppRowShl + 4>(v), v);
+  m *= m;
+  v = fma(m, dpp_d0<kDppRowShl + 8>(v), v);
+  // suffix totals from the first lane of rows 3, 2, 1 to the end of the wave
+  const double t3 = read_lane<48>(v);
+  const double t2 = fma(m16, t3, read_lane<32>(v));
+  const double t1 = fma(m16, t2, read_lane<16>(v));
+  const int row = lane >> 4;
+  return fma(wl, row == 0 ? t1 : row == 1 ? t2 : row == 2 ? t3 : 0., v);
+}
+
 template <typename OP>
 __device__ __forceinline__ double wave_reduce_d(double v, OP op) {
   v = op(v, dpp_d<kDppXor1>(v));
