@@ -38,8 +38,15 @@ struct CommonTables {
   // with A = sqrt(8/3) / 2 and 16 compile-time (C_r, S_r): 2 KB of table per wave instead of 16 KB
   double hann_lane[64][4];      // { A cos th(2l), A sin th(2l), A cos th(2l+1), A sin th(2l+1) }
   double ear_w2[kBins];         // fftearmodel.c:253-256
-  double tw_re[kFrame];         // exp(-2 pi i k / 2048), k = 0..2047
+  double tw_re[kFrame];         // exp(-2 pi i k / 2048), k = 0..2047 (filter-bank tables, tools)
   double tw_im[kFrame];
+  // The front end's twiddle factors, lane-major: every load is one coalesced 16-byte access per lane
+  // (gathers from tw_re / tw_im cost the vector-memory pipe up to 64 cycles per instruction, and that
+  // pipe is what bounds the kernel).  Entry e of lane l is W_2048^(kTwLaneStride[e] * (l & kTwLaneMask[e])):
+  //   0 W_2048^l   1 W_1024^l   2 W_256^(l&15)   3 W_512^l   4 W_64^(l&7)   5 W_16^(l&3)   6 W_64^(l&15)   7 W_256^l
+  // higher powers and the r-dependent parts are products with compile-time constants.
+  double tw_lane[8][64][2];
+  double ear_w2_pair[8][64][2]; // ear_w2 of bin l + 64 q and of its mirror bin (spec_bin(8 + q, l)), q = 0..7
   double ehs_window[256];       // movs.c:1366-1367
 };
 

@@ -6,10 +6,10 @@
 // EHS log-ratio, SURVEY.md Appendix B.10 -- is lost).
 //
 // Per wave (reference fftearmodel.c:433-515 up to `unsmeared_excitation`):
-//   Hann window * samples            :451-452
+//   Hann window * samples            :451-452   (window evaluated from 4 per-lane values)
 //   2048-point real DFT              :457   (as a 1024-point complex Stockham
 //                                            FFT 16x16x4 in registers + LDS and
-//                                            the even/odd split)
+//                                            the even/odd split, two mirror bins per step)
 //   power spectrum * level factor    :464-466
 //   outer/middle ear weighting       :470-472
 //   grouping into critical bands     :604-620
@@ -18,11 +18,17 @@
 //   energy flag                      :508-514
 // plus the frame's stateless MOV ingredients:
 //   ref wave : data-boundary detector      gstpeaq.c:1081-1099 (before the FFT)
+//   both     : totalsnr energies           gstpeaq.c:913-918 (with the frame load)
 //   both     : bandwidths                  movs.c:776-809 (from the spectra in registers)
-//   both     : error harmonic structure    movs.c:1346-1443 (log ratio + autocorrelation
-//                                          shared, the rest on the ref wave)
+//   both     : log ratio of the spectra    movs.c:1383-1391
+//   ref wave : error harmonic structure    movs.c:1279-1315,1393-1441 (correlation through
+//                                          512-point FFTs like the reference, window, 256-point FFT, peak)
 //   test wave: noise-in-bands for NMR      movs.c:992-1000
-//   ref wave : totalsnr energies           gstpeaq.c:913-918
+//
+// What bounds this kernel (measured): not the FP64 pipe and not HBM bandwidth but
+// latency -- of the vector-memory pipe (hence: one coalesced load path, lane-major tables instead
+// of gathers, an L2 prefetch for the workgroups to come) and of the LDS crossbar (hence: DPP /
+// permlane reductions and scans, band sums fetched eight bins at a time).
 //
 // LDS per wave ("unit"), 10304 B: the 8.5 KiB FFT exchange buffer (real and
 // imaginary parts go through it one after the other) is reused for the weighted
@@ -42,27 +48,13 @@ namespace peaq {
 // LDS per wave ("unit"): 1288 doubles = 10304 B.  During the FFT the first 1088 doubles are the
 // exchange buffer (one real component of the 1024 complex points at a time, padded); afterwards
 // Pw[0..775] (weighted power spectrum) followed by 512 doubles of scratch.
-#ifdef PEAQ_FE_W4
-// four waves per SIMD = eight workgroups per CU: at most 20480 B of LDS per workgroup
-constexpr int kPwLen = 769;                   // the last band ends at bin 768 (18 kHz)
-constexpr int kOffPw = 0;
-constexpr int kOffScratch = kPwLen;
-constexpr int kUnitDoubles = kPwLen + 512;    // reference unit: 512 doubles of scratch
-constexpr int kUnit1Doubles = kPwLen + 368;   // test unit: 368 (spreading accumulators + band powers)
-constexpr int kLdsDoubles = kUnitDoubles + kUnit1Doubles;
-constexpr int kWavesPerSimd = 4;
-constexpr bool kEhsTwoBuffers = false;
-static_assert(kUnit1Doubles >= 1088, "the FFT exchange buffer must fit");
-static_assert(kLdsDoubles * 8 <= 20480, "eight workgroups per CU");
-#else
+constexpr int kPrefetchItems = 64;            // L2 prefetch distance in work items (see the kernel)
 constexpr int kUnitDoubles = 1288;
 constexpr int kOffPw = 0;                     // Pw[776]
 constexpr int kOffScratch = 776;              // 512 doubles
 constexpr int kPwLen = 776;
 constexpr int kLdsDoubles = 2 * kUnitDoubles;
 constexpr int kWavesPerSimd = 3;
-constexpr bool kEhsTwoBuffers = true;
-#endif
 
 // W_32^q = exp(-2 pi i q / 32), q = 0..15
 __device__ constexpr double kW32re[16] = {1., 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
@@ -77,6 +69,13 @@ __device__ constexpr double kW32im[16] = {-0., -0.19509032201612826785, -0.38268
                                           -0.38268343236508977173, -0.19509032201612826785};
 
 __device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }   // complex index -> padded slot
+
+// entry e of the lane-major twiddle table (peaq_device.h): one coalesced 16-byte load
+__device__ __forceinline__ cplx tw_lane(const CommonTables* __restrict__ ct, int e, int lane) {
+  const double2 v = *reinterpret_cast<const double2*>(ct->tw_lane[e][lane]);
+  return {v.x, v.y};
+}
+__device__ __forceinline__ cplx csqr(cplx a) { return {a.re * a.re - a.im * a.im, 2. * (a.re * a.im)}; }
 
 // One exchange step of the Stockham FFT through the wave's 8.5 KiB buffer: all 16 points
 // go out at wr(r) and come back from rd(r), first the real then the imaginary parts.
@@ -111,14 +110,14 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double (&p)[
   {
     const int k = lane & 15;
     {
-      // twiddles W_256^(r k) = W_2048^(8 r k), r = 1..15: four table reads (r = 1, 2, 4, 8),
-      // the rest as products -- 4 instead of 15 trips to L2 per lane
+      // twiddles W_256^(r k), r = 1..15: one table read, three squarings (r = 2, 4, 8),
+      // the rest as products
       // (applied as soon as they exist: only w1..w8 stay live, the register budget is 168)
       cplx w[9];
-      w[1] = {ct->tw_re[8 * k], ct->tw_im[8 * k]};
-      w[2] = {ct->tw_re[16 * k], ct->tw_im[16 * k]};
-      w[4] = {ct->tw_re[32 * k], ct->tw_im[32 * k]};
-      w[8] = {ct->tw_re[64 * k], ct->tw_im[64 * k]};
+      w[1] = tw_lane(ct, 2, lane);                   // W_256^k; the other powers by squaring
+      w[2] = csqr(w[1]);
+      w[4] = csqr(w[2]);
+      w[8] = csqr(w[4]);
       w[3] = cmul(w[1], w[2]);
       w[5] = cmul(w[4], w[1]);
       w[6] = cmul(w[4], w[2]);
@@ -137,16 +136,19 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double (&p)[
     exchange16(z, unit, [&](int r) { return j + 16 * r; },
                [&](int s) { return lane + 64 * (s & 3) + 256 * (s >> 2); });
   }
+  {
+    // W_1024^(r i), i = lane + 64 m: W_1024^lane from the table, times W_16^m (constants), squared and cubed
+    constexpr double c1 = 0.92387953251128673848, s1 = 0.38268343236508977173, c2 = 0.70710678118654752440;
+    const cplx wb = tw_lane(ct, 1, lane);
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int i = lane + 64 * m;
-    // W_1024^(r i) = W_2048^(2 r i), r = 1..3: one table read, two products
-    const cplx w1 = {ct->tw_re[2 * i], ct->tw_im[2 * i]};
-    const cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1);
-    z[m + 4] = cmul(z[m + 4], w1);
-    z[m + 8] = cmul(z[m + 8], w2);
-    z[m + 12] = cmul(z[m + 12], w3);
-    dft4(z[m], z[m + 4], z[m + 8], z[m + 12]);
+    for (int m = 0; m < 4; ++m) {
+      const cplx w1 = m == 0 ? wb : m == 1 ? cmul(wb, {c1, -s1}) : m == 2 ? cmul(wb, {c2, -c2}) : cmul(wb, {s1, -c1});
+      const cplx w2 = csqr(w1), w3 = cmul(w2, w1);
+      z[m + 4] = cmul(z[m + 4], w1);
+      z[m + 8] = cmul(z[m + 8], w2);
+      z[m + 12] = cmul(z[m + 12], w3);
+      dft4(z[m], z[m + 4], z[m + 8], z[m + 12]);
+    }
   }
   // z[q] = Z[lane + 64 q].  Even/odd split, two bins per step: with E = (Z[k] + conj Z[1024-k]) / 2,
   // O = (Z[k] - conj Z[1024-k]) / 2i the real signal's spectrum is X[k] = E + W_2048^k O and
@@ -158,7 +160,7 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double (&p)[
   // Slot q of p[] holds bin lane + 64 q, slot 8 + q the mirror bin (spec_bin() below); lane 0's
   // q = 0 mirror would be bin 1024, which nothing reads: it carries the self-mirrored bin 512.
   wave_lds_fence();                                  // the exchange buffer is about to become Pw
-  const cplx wl = {ct->tw_re[lane], ct->tw_im[lane]};
+  const cplx wl = tw_lane(ct, 0, lane);
   const int partner = (64 - lane) & 63;
   const double lf4 = 0.25 * level_factor;
 #pragma unroll
@@ -179,8 +181,9 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double (&p)[
       km = 512;
     }
     p[8 + q] = pm;
-    unit[kOffPw + k] = p[q] * ct->ear_w2[k];                          // fftearmodel.c:470-472
-    if (km < kPwLen) unit[kOffPw + km] = pm * ct->ear_w2[km];
+    const double2 ew = *reinterpret_cast<const double2*>(ct->ear_w2_pair[q][lane]);
+    unit[kOffPw + k] = p[q] * ew.x;                                   // fftearmodel.c:470-472
+    if (km < kPwLen) unit[kOffPw + km] = pm * ew.y;
   }
   wave_lds_fence();
 }
@@ -251,68 +254,42 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
   return base + slot;
 }
 
-// a wave-uniform pointer, pinned to scalar registers (loads then take the base + 32-bit lane offset form)
-__device__ __forceinline__ const float* uniform_ptr(const float* p) {
-  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
-}
+// ---------------------------------------------------------------------------
+// Frame access.  A frame is read through a raw buffer resource (scalar registers: base = the
+// frame's first sample, size = what is left of the signal from there, at most one frame): lanes
+// add 32-bit offsets, and everything beyond the signal's end reads as zero -- the zero padding of
+// the flush frame (gstpeaq.c:733-738) costs nothing and there is only one load path (gfx950
+// checks the range of a multi-dword buffer load dword by dword, and dword alignment is enough).
+// ---------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// One frame of one signal: `p` points at the frame's first sample (channel 0), `left` samples
-// of the signal remain from there on.  Both are wave-uniform, all lane arithmetic is 32-bit.
 struct FrameSrc {
-  const float* p;
-  int left;                                          // may be <= 0 or > 2048
+  __amdgpu_buffer_rsrc_t rs;
   int channels, chan;
-  bool whole;
-  // samples 2n and 2n+1 of the frame; WHOLE: all 2048 samples exist and the start is aligned
-  template <bool WHOLE>
-  __device__ __forceinline__ void load2(int n, float& x0, float& x1) const {
-#ifdef PEAQ_FE_NOLOAD                                // experiment: how much of the kernel is load latency
-    x0 = (float)n * 1e-4f + (float)chan;
-    x1 = (float)left * 1e-6f - x0;
-    return;
-#endif
-    if (WHOLE) {
-#ifdef PEAQ_FE_BUFLOAD
-      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000);
-      if (channels == 1) {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, n * 8, 0, 0);
-        x0 = __uint_as_float(v.x);
-        x1 = __uint_as_float(v.y);
-      } else {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, n * 16, 0, 0);
-        x0 = __uint_as_float(chan ? v.y : v.x);
-        x1 = __uint_as_float(chan ? v.w : v.z);
-      }
-#else
-      if (channels == 1) {
-        const float2 v = reinterpret_cast<const float2*>(p)[n];
-        x0 = v.x;
-        x1 = v.y;
-      } else {
-        const float4 v = reinterpret_cast<const float4*>(p)[n];
-        x0 = chan ? v.y : v.x;
-        x1 = chan ? v.w : v.z;
-      }
-#endif
-    } else {                                         // zero-padded flush frame (gstpeaq.c:733-738)
-      const int i0 = 2 * n, i1 = i0 + 1;
-      x0 = i0 < left ? p[i0 * channels + chan] : 0.f;
-      x1 = i1 < left ? p[i1 * channels + chan] : 0.f;
-    }
-  }
+  // frame starting at sample s0 of a signal with n_valid samples per channel
   __device__ __forceinline__ void set(const float* x, long long s0, long long n_valid, int channels_, int chan_) {
     channels = channels_;
     chan = chan_;
-    p = uniform_ptr(x + s0 * channels);
-    const long long l = n_valid - s0;
-    left = l < 0 ? 0 : l > kFrame ? kFrame : (int)l;
-    // vector loads need the whole frame in range and a 8 B (mono) / 16 B (stereo) aligned start
-    whole = left == kFrame && (reinterpret_cast<size_t>(p) & (channels == 1 ? 7 : 15)) == 0;
+    long long l = n_valid - s0;
+    l = l < 0 ? 0 : l > kFrame ? kFrame : l;
+    const unsigned long long v = reinterpret_cast<unsigned long long>(x + s0 * channels);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);           // wave-uniform by construction: say so
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    float* p = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+    rs = __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane((int)l * channels * 4), 0x00020000);
+  }
+  // samples 2 n and 2 n + 1 of this channel
+  __device__ __forceinline__ void load2(int n, float& x0, float& x1) const {
+    if (channels == 1) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, n * 8, 0, 0);
+      x0 = __uint_as_float(v.x);
+      x1 = __uint_as_float(v.y);
+    } else {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, n * 16, 0, 0);
+      x0 = __uint_as_float(chan ? v.y : v.x);
+      x1 = __uint_as_float(chan ? v.w : v.z);
+    }
   }
 };
 
@@ -365,22 +342,36 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
   const size_t pair_off = (size_t)pair * a.pair_stride * a.channels;
   FrameSrc src_ref, src_test;
   {
-#ifdef PEAQ_FE_SAMEFRAME                             // experiment: every workgroup reads the same (cache-resident) frame
-    const long long s0 = 0;
-    src_ref.set(a.ref, s0 + a.off_ref, (long long)n_ref, a.channels, chan);
-    src_test.set(a.test, s0 + a.off_test, (long long)n_test, a.channels, chan);
-    if (false)
-#else
     const long long s0 = (long long)(frame - frame_origin) * kHop;
-#endif
-    {
     src_ref.set(a.ref + pair_off, s0 + a.off_ref, (long long)n_ref, a.channels, chan);
     src_test.set(a.test + pair_off, s0 + a.off_test, (long long)n_test, a.channels, chan);
-    }
   }
   const FrameSrc& src = sig ? src_test : src_ref;
   double* __restrict__ rec =
       a.records + ((size_t)(pair * a.frames_per_launch + fl) * a.channels + chan) * kRecDoubles;
+  // ---- L2 prefetch for a workgroup further down this XCD's queue.  A fresh wave has nothing to do
+  // until its frame has arrived, and under load the half of it that no earlier frame has touched
+  // takes thousands of cycles to come from HBM.  So every channel-0 workgroup touches, one dword per
+  // 128-byte line, the not yet seen samples of the frame that the workgroup kPrefetchItems items
+  // further on will load: by then they sit in this XCD's L2 (items are dealt to an XCD in order).
+  // The value is never used; one compare at the end of the kernel keeps the loads alive.
+  float pf_keep = 0.f;
+  if (chan == 0 && !a.pair_frame0) {
+    const unsigned it2 = item + kPrefetchItems;
+    if (it2 < gridDim.x) {
+      const unsigned fl2 = (it2 / a.channels) % a.frames_per_launch;
+      const unsigned pair2 = it2 / (a.channels * a.frames_per_launch);
+      const unsigned n2 = sig ? (a.n_test ? a.n_test[pair2] : a.n_uniform_test) : (a.n_ref ? a.n_ref[pair2] : a.n_uniform_ref);
+      // frame 0 of a chunk is new as a whole, later ones share their first half with their predecessor
+      const long long s2 = (long long)(a.frame0 + fl2 - a.frame_origin) * kHop + (fl2 == 0 ? 0 : kHop);
+      FrameSrc pf;
+      pf.set((sig ? a.test : a.ref) + (size_t)pair2 * a.pair_stride * a.channels, s2 + (sig ? a.off_test : a.off_ref),
+             (long long)n2, a.channels, 0);
+      pf_keep = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pf.rs, lane * 128, 0, 0));
+      if (fl2 == 0 && a.channels == 2)               // 16 KiB: a second row of 64 lines
+        pf_keep += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pf.rs, (64 + lane) * 128, 0, 0));
+    }
+  }
 
   // ---- load + window (fftearmodel.c:451-452), energy flag (:508-514), totalsnr energies over the hop
   // (gstpeaq.c:913-918; float products): the reference wave sums ref^2 from its own samples, the test
@@ -402,16 +393,16 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
                                  -0.9229222721777677728372, -0.705205101457706221079, -0.3800232782373413192215};
   const double2 hl0 = *reinterpret_cast<const double2*>(&ct->hann_lane[lane][0]);
   const double2 hl1 = *reinterpret_cast<const double2*>(&ct->hann_lane[lane][2]);
+  FE_MARK(13);                                       // work-item decoding, pointers
   cplx z[16];
   float amax = 0.f;
   double energy = 0., hop = 0.;                      // hop: sum ref^2 (reference wave) / sum (ref - test)^2 (test wave)
-  auto load_frame = [&](auto whole) {
-    constexpr bool W = decltype(whole)::value;
+  {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = lane + 64 * r;
       float x0, x1;
-      src.template load2<W>(n, x0, x1);
+      src.load2(n, x0, x1);
       const double w0 = fma(hl0.y, kHannS[r], fma(-hl0.x, kHannC[r], kHannA));
       const double w1 = fma(hl1.y, kHannS[r], fma(-hl1.x, kHannC[r], kHannA));
       z[r] = {w0 * (double)x0, w1 * (double)x1};
@@ -423,7 +414,7 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
         hop += (double)(x1 * x1);
       } else {
         float r0, r1;
-        src_ref.template load2<W>(n, r0, r1);
+        src_ref.load2(n, r0, r1);
         hop += (double)((r0 - x0) * (r0 - x0));
         hop += (double)((r1 - x1) * (r1 - x1));
       }
@@ -431,12 +422,7 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
       // is excluded because the first tested window is [1..5]
       amax = fmaxf(amax, n == 0 ? fabsf(x1) : fmaxf(fabsf(x0), fabsf(x1)));
     }
-  };
-  FE_MARK(13);                                       // work-item decoding, pointers
-  if (src.whole && (sig == 0 || src_ref.whole))      // one uniform branch, not one per sample
-    load_frame(std::true_type{});
-  else
-    load_frame(std::false_type{});
+  }
 #ifdef PEAQ_FE_PROFILE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -460,7 +446,7 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
       for (int r = 0; r < 16; ++r) {
         const int n = lane_q + 64 * r;
         float x0, x1;
-        src.template load2<false>(n, x0, x1);        // rare path: the guarded loads serve both cases
+        src.load2(n, x0, x1);
         reinterpret_cast<float2*>(ax)[n] = make_float2(fabsf(x0), fabsf(x1));
       }
       wave_lds_fence();
@@ -688,40 +674,25 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
     // exchange steps of the 512-point Stockham FFT; the index swizzles keep the 8-byte stores of a
     // 16-lane group on distinct banks (reads lane + 64 r are consecutive anyway)
     auto exchange8 = [&](auto wr, auto swz) {
-      if (kEhsTwoBuffers) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int i = swz(wr(r));
-          sa[i] = u[r].re;
-          sb[i] = u[r].im;
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int i = swz(lane + 64 * r);
-          u[r] = {sa[i], sb[i]};
-        }
-        wave_lds_fence();
-      } else {                                       // one 512-double buffer: real parts, then imaginary parts
-#pragma unroll
-        for (int r = 0; r < 8; ++r) sa[swz(wr(r))] = u[r].re;
-        wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 8; ++r) u[r].re = sa[swz(lane + 64 * r)];
-        wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 8; ++r) sa[swz(wr(r))] = u[r].im;
-        wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 8; ++r) u[r].im = sa[swz(lane + 64 * r)];
-        wave_lds_fence();
+      for (int r = 0; r < 8; ++r) {
+        const int i = swz(wr(r));
+        sa[i] = u[r].re;
+        sb[i] = u[r].im;
       }
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int i = swz(lane + 64 * r);
+        u[r] = {sa[i], sb[i]};
+      }
+      wave_lds_fence();
     };
-    auto twiddle8 = [&](int step) {                  // u[r] *= W_2048^(r step), r = 1..7
+    auto twiddle8 = [&](cplx w1) {                   // u[r] *= w1^r, r = 1..7
       cplx w[8];
-      w[1] = {ct->tw_re[step], ct->tw_im[step]};
-      w[2] = {ct->tw_re[2 * step], ct->tw_im[2 * step]};
-      w[4] = {ct->tw_re[4 * step], ct->tw_im[4 * step]};
+      w[1] = w1;
+      w[2] = csqr(w[1]);
+      w[4] = csqr(w[2]);
       w[3] = cmul(w[1], w[2]);
       w[5] = cmul(w[4], w[1]);
       w[6] = cmul(w[4], w[2]);
@@ -733,12 +704,13 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
     exchange8([&](int r) { return 8 * lane + r; }, [](int i) { return i ^ ((i >> 4) & 7); });
     {
       const int k = lane & 7;
-      twiddle8(32 * k);                                              // W_64^(r k)
+      twiddle8(tw_lane(ct, 4, lane));                                // W_64^(r k)
       dft8(u);                                                       // size 8 -> out[8 (lane - k) + k + 8 r]
       const int j = (lane - k) * 8 + k;
       exchange8([&](int r) { return j + 8 * r; }, [](int i) { return i ^ (((i >> 6) & 1) << 3); });
     }
-    twiddle8(4 * lane);                                              // W_512^(r lane)
+    const cplx w512 = tw_lane(ct, 3, lane);                          // W_512^lane
+    twiddle8(w512);                                                  // W_512^(r lane)
     dft8(u);                                                         // u[r] = (A + i B)[lane + 64 r]
     FE_MARK(10);                                     // reference wave: 512-point FFT
     // Separate the two spectra and multiply, bins k = lane + 64 r < 256 (and 256 itself in lane 0);
@@ -766,11 +738,12 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
     for (int r = 0; r < 4; ++r) {
       cplx cm = {__shfl(cc[3 - r].re, partner, 64), __shfl(cc[3 - r].im, partner, 64)};
       if (lane == 0) cm = r == 0 ? cplx{c256, 0.} : cc[4 - r];
-      const int k = lane + 64 * r;
       const cplx e = {cc[r].re + cm.re, cc[r].im - cm.im};
       const cplx od = {cc[r].re - cm.re, cc[r].im + cm.im};
-      const cplx wk = {ct->tw_re[4 * k], -ct->tw_im[4 * k]};         // W_512^-k = conj W_2048^(4 k)
-      const cplx o = cmul(od, wk);
+      // W_512^-k = conj(W_512^lane W_8^r)
+      constexpr double c8 = 0.70710678118654752440;
+      const cplx wkf = r == 0 ? w512 : r == 1 ? cmul(w512, {c8, -c8}) : r == 2 ? cmul_mi(w512) : cmul(w512, {-c8, -c8});
+      const cplx o = cmul(od, {wkf.re, -wkf.im});
       v[r] = {e.re - o.im, -(e.im + o.re)};                          // conj(E + i O)
     }
     wave_lds_fence();
@@ -786,11 +759,11 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
             const double2 x = xb[lane + 64 * r];
             w[r] = {x.x, x.y};
           }
-#pragma unroll
-          for (int r = 1; r < 4; ++r) {
-            const int t = r * k * (512 >> (2 * pass));   // W_{4p}^(r k) = W_2048^(r k 512/p)
-            w[r] = cmul(w[r], {ct->tw_re[t], ct->tw_im[t]});
-          }
+          // W_{4p}^(r k): W_16^(lane & 3), W_64^(lane & 15), W_256^lane from the table, squared and cubed
+          const cplx t1 = tw_lane(ct, 4 + pass, lane), t2 = csqr(t1), t3 = cmul(t2, t1);
+          w[1] = cmul(w[1], t1);
+          w[2] = cmul(w[2], t2);
+          w[3] = cmul(w[3], t3);
         }
         dft4(w[0], w[1], w[2], w[3]);
         if (pass < 3) {
@@ -860,6 +833,7 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
     if (lane == 0) rec[kRecEhs] = best;
     FE_MARK(12);                                     // reference wave: normalise, window, 256-point FFT, peak
   }
+  if (pf_keep == 123456.789f) rec[kRecScalars + 15] = 1.;   // never true (samples lie in [-1, 1]): keeps the prefetch alive
 }
 
 hipError_t launch_frontend(int bands, const FrontendArgs& a, unsigned n_pairs, hipStream_t stream) {

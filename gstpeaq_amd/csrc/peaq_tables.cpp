@@ -222,6 +222,22 @@ void build_common_tables(CommonTables& c) {
     const double w = ear_weight_db_to_lin(static_cast<double>(k) * kFs / n);
     c.ear_w2[k] = w * w;
   }
+  {
+    const int stride[8] = {1, 2, 8, 4, 32, 128, 32, 8}, mask[8] = {63, 63, 15, 63, 7, 3, 15, 63};
+    for (int e = 0; e < 8; ++e)
+      for (int l = 0; l < 64; ++l) {
+        const int k = stride[e] * (l & mask[e]);
+        c.tw_lane[e][l][0] = c.tw_re[k];
+        c.tw_lane[e][l][1] = c.tw_im[k];
+      }
+    for (int q = 0; q < 8; ++q)
+      for (int l = 0; l < 64; ++l) {
+        const int k = l + 64 * q;
+        const int km = (l == 0 && q == 0) ? 512 : 1024 - k;       // spec_bin(8 + q, l) in peaq_frontend.hip
+        c.ear_w2_pair[q][l][0] = c.ear_w2[k];
+        c.ear_w2_pair[q][l][1] = c.ear_w2[km];
+      }
+  }
   for (int i = 0; i < 256; ++i)  // CENTER_EHS_CORRELATION_WINDOW 0
     c.ehs_window[i] = 0.81649658092773 * (1.0 - std::cos(2 * kPi * i / 255.0)) / 256.0;
 }
