@@ -111,7 +111,9 @@ def test_backend_patterns_match_oracle_per_frame(gpu, case):
     np.testing.assert_allclose(d["adapted_test"][:, 0], ad_t, rtol=1e-9)
     for sig, o in (("ref", o_ref), ("test", o_test)):
         mod, loud = orc.modproc(NB, o["unsmeared"])
-        np.testing.assert_allclose(d[f"mod_{sig}"][:, 0], mod, rtol=1e-9, atol=1e-300)
+        # the modulation is driven by |L - L_prev| (modpatt.c:231): for a stationary signal that difference
+        # cancels to ~1e-5 of L, and the last-bit differences of the two spectra show at 1e-9 relative
+        np.testing.assert_allclose(d[f"mod_{sig}"][:, 0], mod, rtol=1e-7, atol=1e-12)
         np.testing.assert_allclose(d[f"avgloud_{sig}"][:, 0], loud, rtol=1e-9)
     # total loudness is only evaluated until the gate opens (gstpeaq.c:841-845)
     gate = np.flatnonzero((o_ref["loudness"] > 0.1) & (o_test["loudness"] > 0.1))
