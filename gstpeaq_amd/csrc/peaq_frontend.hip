@@ -322,10 +322,17 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
   const BandTables* __restrict__ bt = a.bands;
 
   // ---- which (pair, frame, channel) -------------------------------------------
+  // item = (pair * frames_per_launch + fl) * channels + chan, taken apart without integer divisions
+  // (channels is 1 or 2; the launch carries the reciprocal of frames_per_launch)
+  auto decode = [&](unsigned it, unsigned& pair_, unsigned& fl_) {
+    const unsigned t = it >> (a.channels - 1);
+    pair_ = a.frames_per_launch == 1 ? t : __umulhi(t, a.fpl_magic);   // (the reciprocal of 1 does not fit)
+    fl_ = t - pair_ * a.frames_per_launch;
+    return (int)(it & (unsigned)(a.channels - 1));
+  };
   const unsigned item = xcd_remap(blockIdx.x, gridDim.x);
-  const int chan = item % a.channels;
-  const unsigned fl = (item / a.channels) % a.frames_per_launch;
-  const unsigned pair = item / (a.channels * a.frames_per_launch);
+  unsigned pair, fl;
+  const int chan = decode(item, pair, fl);
   const unsigned n_ref = a.n_ref ? a.n_ref[pair] : a.n_uniform_ref;
   const unsigned n_test = a.n_test ? a.n_test[pair] : a.n_uniform_test;
   unsigned frame, frame_origin;
@@ -349,30 +356,6 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
   const FrameSrc& src = sig ? src_test : src_ref;
   double* __restrict__ rec =
       a.records + ((size_t)(pair * a.frames_per_launch + fl) * a.channels + chan) * kRecDoubles;
-  // ---- L2 prefetch for a workgroup further down this XCD's queue.  A fresh wave has nothing to do
-  // until its frame has arrived, and under load the half of it that no earlier frame has touched
-  // takes thousands of cycles to come from HBM.  So every channel-0 workgroup touches, one dword per
-  // 128-byte line, the not yet seen samples of the frame that the workgroup kPrefetchItems items
-  // further on will load: by then they sit in this XCD's L2 (items are dealt to an XCD in order).
-  // The value is never used; one compare at the end of the kernel keeps the loads alive.
-  float pf_keep = 0.f;
-  if (chan == 0 && !a.pair_frame0) {
-    const unsigned it2 = item + kPrefetchItems;
-    if (it2 < gridDim.x) {
-      const unsigned fl2 = (it2 / a.channels) % a.frames_per_launch;
-      const unsigned pair2 = it2 / (a.channels * a.frames_per_launch);
-      const unsigned n2 = sig ? (a.n_test ? a.n_test[pair2] : a.n_uniform_test) : (a.n_ref ? a.n_ref[pair2] : a.n_uniform_ref);
-      // frame 0 of a chunk is new as a whole, later ones share their first half with their predecessor
-      const long long s2 = (long long)(a.frame0 + fl2 - a.frame_origin) * kHop + (fl2 == 0 ? 0 : kHop);
-      FrameSrc pf;
-      pf.set((sig ? a.test : a.ref) + (size_t)pair2 * a.pair_stride * a.channels, s2 + (sig ? a.off_test : a.off_ref),
-             (long long)n2, a.channels, 0);
-      pf_keep = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pf.rs, lane * 128, 0, 0));
-      if (fl2 == 0 && a.channels == 2)               // 16 KiB: a second row of 64 lines
-        pf_keep += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pf.rs, (64 + lane) * 128, 0, 0));
-    }
-  }
-
   // ---- load + window (fftearmodel.c:451-452), energy flag (:508-514), totalsnr energies over the hop
   // (gstpeaq.c:913-918; float products): the reference wave sums ref^2 from its own samples, the test
   // wave fetches the reference's first 1024 samples in the same batch of loads for (ref - test)^2.
@@ -423,6 +406,30 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
       amax = fmaxf(amax, n == 0 ? fabsf(x1) : fmaxf(fabsf(x0), fabsf(x1)));
     }
   }
+  // ---- L2 prefetch for a workgroup further down this XCD's queue.  A fresh wave has nothing to do
+  // until its frame has arrived, and under load the half of it that no earlier frame has touched
+  // takes thousands of cycles to come from HBM.  So every channel-0 workgroup touches, one dword per
+  // 128-byte line, the not yet seen samples of the frame that the workgroup kPrefetchItems items
+  // further on will load: by then they sit in this XCD's L2 (items are dealt to an XCD in order).
+  // The value is never used; one compare at the end of the kernel keeps the loads alive.
+  float pf_keep = 0.f;
+  if (chan == 0 && !a.pair_frame0) {
+    const unsigned it2 = item + kPrefetchItems;
+    if (it2 < gridDim.x) {
+      unsigned pair2, fl2;
+      decode(it2, pair2, fl2);
+      const unsigned n2 = sig ? (a.n_test ? a.n_test[pair2] : a.n_uniform_test) : (a.n_ref ? a.n_ref[pair2] : a.n_uniform_ref);
+      // frame 0 of a chunk is new as a whole, later ones share their first half with their predecessor
+      const long long s2 = (long long)(a.frame0 + fl2 - a.frame_origin) * kHop + (fl2 == 0 ? 0 : kHop);
+      FrameSrc pf;
+      pf.set((sig ? a.test : a.ref) + (size_t)pair2 * a.pair_stride * a.channels, s2 + (sig ? a.off_test : a.off_ref),
+             (long long)n2, a.channels, 0);
+      pf_keep = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pf.rs, lane * 128, 0, 0));
+      if (fl2 == 0 && a.channels == 2)               // 16 KiB: a second row of 64 lines
+        pf_keep += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pf.rs, (64 + lane) * 128, 0, 0));
+    }
+  }
+
 #ifdef PEAQ_FE_PROFILE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -839,11 +846,14 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
 hipError_t launch_frontend(int bands, const FrontendArgs& a, unsigned n_pairs, hipStream_t stream) {
   const unsigned grid = n_pairs * a.frames_per_launch * a.channels;
   if (grid == 0) return hipSuccess;
+  if ((unsigned long long)n_pairs * a.frames_per_launch * a.channels >= (1ull << 26)) return hipErrorInvalidValue;
+  FrontendArgs args = a;
+  args.fpl_magic = (unsigned)(((1ull << 32) + a.frames_per_launch - 1) / a.frames_per_launch);
   const size_t lds = kLdsDoubles * sizeof(double);
   if (bands == 109)
-    hipLaunchKernelGGL(frontend_kernel<109>, dim3(grid), dim3(128), lds, stream, a);
+    hipLaunchKernelGGL(frontend_kernel<109>, dim3(grid), dim3(128), lds, stream, args);
   else if (bands == 55)
-    hipLaunchKernelGGL(frontend_kernel<55>, dim3(grid), dim3(128), lds, stream, a);
+    hipLaunchKernelGGL(frontend_kernel<55>, dim3(grid), dim3(128), lds, stream, args);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();

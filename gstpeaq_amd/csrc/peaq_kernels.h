@@ -25,6 +25,8 @@ struct FrontendArgs {
   int channels;
   unsigned frame0;              // first frame of this launch
   unsigned frames_per_launch;
+  unsigned fpl_magic;           // ceil(2^32 / frames_per_launch): x / frames_per_launch = mulhi(x, magic) for x < 2^26
+                                // (filled in by launch_frontend)
   double level_factor;          // fftearmodel.c:312-313
   const CommonTables* common;
   const BandTables* bands;      // FFT model, 109 or 55 bands
