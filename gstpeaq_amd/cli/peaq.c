@@ -10,9 +10,14 @@
  * reads RIFF/WAVE itself (PCM 8/16/24/32 bit and IEEE float 32/64, mono or
  * stereo) and feeds the engine's session API directly, so that it works on a
  * box without gst-plugins-good.  Integer PCM is scaled by 1/2^(bits-1) like
- * audioconvert does (S16 -> x/32768, verified in SURVEY.md 8(c)).  Files must be
- * 48 kHz (the ear models are defined for 48 kHz only, earmodel.c:43); there is
- * no resampler here.
+ * audioconvert does (S16 -> x/32768, verified in SURVEY.md 8(c)).  The ear
+ * models are defined for 48 kHz only (earmodel.c:43): files at another rate are
+ * converted first, as the reference's `audioresample` does -- here with a
+ * Kaiser-windowed sinc interpolator (64 zero crossings, stop band below -120 dB,
+ * cutoff at 0.96 of the lower Nyquist frequency).  The two resamplers are
+ * different filters, so for such files ODG/DI agree with the reference only to
+ * a few 1e-3, not digit for digit (48 kHz files: digit for digit); pass
+ * --no-resample to refuse them instead.
  */
 #include <math.h>
 #include <stdint.h>
@@ -121,6 +126,66 @@ wav_read (const char *path, wav_t * w)
   return -1;
 }
 
+/* ---- sample-rate conversion to 48 kHz (stands in for audioresample, peaq.c:154-209) ----
+ * y[m] = sum_n x[n] h(m / 48000 - n / rate), h = Kaiser-windowed sinc with the cutoff below the
+ * lower of the two Nyquist frequencies, evaluated directly in double precision (a file is
+ * converted once; no polyphase table needed). */
+static double
+bessel_i0 (double x)
+{
+  double sum = 1., term = 1.;
+  int k;
+  for (k = 1; k < 60; k++) {
+    term *= (x / (2. * k)) * (x / (2. * k));
+    sum += term;
+    if (term < 1e-18 * sum)
+      break;
+  }
+  return sum;
+}
+
+static int
+resample_to_48k (wav_t * w)
+{
+  const double ratio = 48000. / w->rate;                        /* output samples per input sample */
+  const double fc = 0.96 * 0.5 * (ratio < 1. ? ratio : 1.);     /* cutoff in cycles per INPUT sample */
+  const int zc = 64;                                            /* zero crossings on each side */
+  const double half = zc / (2. * fc);                           /* half width of the kernel in input samples */
+  const double beta = 12.9846;                                  /* Kaiser: -125 dB stop band */
+  const double i0b = bessel_i0 (beta);
+  const size_t out_frames = (size_t) floor ((double) w->frames * ratio);
+  float *out = malloc ((out_frames ? out_frames : 1) * w->channels * sizeof (float));
+  size_t m;
+  int c;
+  if (!out)
+    return -1;
+  for (m = 0; m < out_frames; m++) {
+    const double t = (double) m / ratio;                        /* position in input samples */
+    long n0 = (long) ceil (t - half), n1 = (long) floor (t + half), n;
+    double acc[2] = { 0., 0. };
+    if (n0 < 0)
+      n0 = 0;
+    if (n1 > (long) w->frames - 1)
+      n1 = (long) w->frames - 1;
+    for (n = n0; n <= n1; n++) {
+      const double d = t - (double) n, u = d / half;
+      const double arg = 2. * M_PI * fc * d;
+      const double snc = fabs (arg) < 1e-12 ? 1. : sin (arg) / arg;
+      const double win = bessel_i0 (beta * sqrt (1. - u * u > 0. ? 1. - u * u : 0.)) / i0b;
+      const double h = 2. * fc * snc * win;
+      for (c = 0; c < w->channels; c++)
+        acc[c] += h * w->samples[(size_t) n * w->channels + c];
+    }
+    for (c = 0; c < w->channels; c++)
+      out[m * w->channels + c] = (float) acc[c];
+  }
+  free (w->samples);
+  w->samples = out;
+  w->frames = out_frames;
+  w->rate = 48000;
+  return 0;
+}
+
 static void
 usage (const char *prog)
 {
@@ -130,13 +195,14 @@ usage (const char *prog)
       "  --version     print version information\n"
       "  --advanced    use advanced version\n"
       "  --basic       use basic version (default)\n"
-      "  --level=DB    playback level in dB SPL of a full-scale sine (default 92)\n", prog);
+      "  --level=DB    playback level in dB SPL of a full-scale sine (default 92)\n"
+      "  --no-resample refuse files that are not sampled at 48 kHz instead of converting them\n", prog);
 }
 
 int
 main (int argc, char **argv)
 {
-  int advanced = 0, i, nfiles = 0, rc;
+  int advanced = 0, i, nfiles = 0, rc, allow_resample = 1;
   double level = 92.;
   const char *files[2] = { NULL, NULL };
   wav_t ref, test;
@@ -152,6 +218,8 @@ main (int argc, char **argv)
       advanced = 0;
     else if (!strncmp (argv[i], "--level=", 8))
       level = atof (argv[i] + 8);
+    else if (!strcmp (argv[i], "--no-resample"))
+      allow_resample = 0;
     else if (!strcmp (argv[i], "--version")) {
       printf ("peaq (gstpeaq_amd) %s\n", peaq_version ());
       return 0;
@@ -173,8 +241,14 @@ main (int argc, char **argv)
   if (wav_read (files[0], &ref) || wav_read (files[1], &test))
     return 2;
   if (ref.rate != 48000 || test.rate != 48000) {
-    fprintf (stderr, "Error: both files must be sampled at 48 kHz (got %d and %d Hz)\n", ref.rate, test.rate);
-    return 2;
+    if (!allow_resample || ref.rate < 8000 || test.rate < 8000) {
+      fprintf (stderr, "Error: both files must be sampled at 48 kHz (got %d and %d Hz)\n", ref.rate, test.rate);
+      return 2;
+    }
+    if ((ref.rate != 48000 && resample_to_48k (&ref)) || (test.rate != 48000 && resample_to_48k (&test))) {
+      fprintf (stderr, "Error: out of memory while resampling\n");
+      return 2;
+    }
   }
   if (ref.channels != test.channels) {
     /* the element negotiates equal channel counts via audioconvert; up-mix the mono side */

@@ -185,7 +185,12 @@ constexpr int kTileSub = 60;                        // sub-samples per tile (10 
 constexpr int kTileBlocks = 10;
 constexpr int kWin = (kTileSub - 1) * 32 + kFbRing + 1;   // 3345 filtered samples
 constexpr int kWinCols = (kWin + 31) / 32;          // 105
-constexpr int kWinRow = kWinCols + 1;               // row stride in doubles (106)
+// row stride in doubles.  The four delay groups of a wave (lanes 16 g .. 16 g + 15) read 16 consecutive
+// doubles each from four consecutive rows in one ds_read_b64: with a stride of 16 mod 32 doubles two
+// neighbouring rows cover all 64 banks between them, so both halves of the wave are conflict free
+// (the old stride 106 made them overlap on 12 banks: 30 % of the LDS cycles were conflicts)
+constexpr int kWinRow = 112;
+static_assert(kWinRow > kWinCols && kWinRow % 32 == 16, "window rows: long enough, and two rows apart = 32 banks");
 constexpr int kACols = 64;                          // A[band][time] row stride
 
 // window sample with uniform index part u (the lane adds its time point): row u mod 32,
@@ -378,18 +383,18 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
     for (int i = 0; i < 10; ++i) sh.hist[tid][i] = st->e0_hist[tid][i];
   }
   double exc = tid < kFbBands ? st->excitation[tid] : 0.;
-  // (1-A)^(t+1): decay of the slope-filter state that enters a tile
-  double decay;
-  {
+  // (1-A)^(t+1): decay of the slope-filter state that enters a tile; (1-A)^((t & 15) + 1) for the row carries
+  auto pow_1ma = [](int e) {
     double p = 1. - kSlopeA, acc = 1.;
-    int e = lane + 1;
     while (e) {
       if (e & 1) acc *= p;
       p *= p;
       e >>= 1;
     }
-    decay = acc;
-  }
+    return acc;
+  };
+  const double decay = pow_1ma(lane + 1), decay_row = pow_1ma((lane & 15) + 1);
+  constexpr double kM1 = 1. - kSlopeA, kM2 = kM1 * kM1, kM4 = kM2 * kM2, kM8 = kM4 * kM4, kM16 = kM8 * kM8;
 
   constexpr double kC1 = -2. * kLnDist / 2.302585092994046;         // -0.2 * 10 / ln 10 * ln DIST
   double c0[10];
@@ -478,13 +483,7 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       // pow(DIST, s), s = max(4, 24 + 230/fc - 0.2 L), L = 10 log10 |A|^2 (fbearmodel.c:329-333), as
       // exp(min(4 ln DIST, ln DIST (24 + 230/fc) - 2 ln DIST / ln 10 * ln |A|^2))  (ln DIST < 0)
       const double dist_s = exp_fast(fmin(4. * kLnDist, c0[i] + kC1 * log_nonneg(re[i] * re[i] + im[i] * im[i])));
-      double v = kSlopeA * dist_s, m = 1. - kSlopeA;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const double o = __shfl_up(v, d, 64);
-        if (lane >= d) v += m * o;
-        m *= m;
-      }
+      const double v = wave_prefix_geometric(kSlopeA * dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
       const double cu = v + decay * sh.cu[b];
       const double carry = __shfl(cu, nvs - 1, 64);
       if (lane == 0) sh.cu[b] = carry;                               // only this wave touches cu[b]

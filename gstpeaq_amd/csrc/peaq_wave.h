@@ -165,6 +165,22 @@ __device__ __forceinline__ double wave_suffix_geometric(double v, double m, int 
   return fma(wl, row == 0 ? t1 : row == 1 ? t2 : row == 2 ? t3 : 0., v);
 }
 
+// weighted prefix sum: lane i gets sum_{j <= i} m^(i - j) v_j.  m1..m8 = m, m^2, m^4, m^8 and
+// wl = m^((lane & 15) + 1) are the caller's (they are loop invariants where this is used).
+__device__ __forceinline__ double wave_prefix_geometric(double v, double m1, double m2, double m4, double m8, double m16,
+                                                        double wl, int lane) {
+  v = fma(m1, dpp_d0<kDppRowShr + 1>(v), v);
+  v = fma(m2, dpp_d0<kDppRowShr + 2>(v), v);
+  v = fma(m4, dpp_d0<kDppRowShr + 4>(v), v);
+  v = fma(m8, dpp_d0<kDppRowShr + 8>(v), v);
+  // prefix totals at the last lane of rows 0, 1, 2
+  const double t0 = read_lane<15>(v);
+  const double t1 = fma(m16, t0, read_lane<31>(v));
+  const double t2 = fma(m16, t1, read_lane<47>(v));
+  const int row = lane >> 4;
+  return fma(wl, row == 0 ? 0. : row == 1 ? t0 : row == 2 ? t1 : t2, v);
+}
+
 template <typename OP>
 __device__ __forceinline__ double wave_reduce_d(double v, OP op) {
   v = op(v, dpp_d<kDppXor1>(v));
