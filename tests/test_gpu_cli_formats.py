@@ -87,24 +87,43 @@ def write_wav_rate(path, x, rate):
     Path(path).write_bytes(b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks)
 
 
+def resample_np(x, rate):
+    """numpy transcription of resample_to_48k() in gstpeaq_amd/cli/peaq.c (Kaiser-windowed sinc, 64 zero crossings)"""
+    from scipy.special import i0
+    ratio = 48000. / rate
+    fc, zc, beta = 0.96 * 0.5 * min(ratio, 1.0), 64, 12.9846
+    half = zc / (2 * fc)
+    n_out = int(np.floor(len(x) * ratio))
+    out = np.zeros((n_out, x.shape[1]))
+    for m in range(n_out):
+        t = m / ratio
+        n = np.arange(max(int(np.ceil(t - half)), 0), min(int(np.floor(t + half)), len(x) - 1) + 1)
+        d = t - n
+        arg = 2 * np.pi * fc * d
+        snc = np.where(np.abs(arg) < 1e-12, 1.0, np.sin(arg) / np.where(arg == 0, 1, arg))
+        win = i0(beta * np.sqrt(np.maximum(1 - (d / half) ** 2, 0))) / i0(beta)
+        out[m] = (2 * fc * snc * win) @ x[n]
+    return out.astype(np.float32)
+
+
 def test_cli_converts_44100_hz_files(tmp_path):
-    """a 44.1 kHz pair (which the reference accepts through audioresample): band-limited tones resampled by
-    the CLI must score like the same tones generated at 48 kHz directly (the resampler is transparent to
-    1e-2 ODG for in-band material), and --no-resample must refuse the files with exit status 2"""
-    def tones(rate, seconds=2.0):
-        t = np.arange(int(rate * seconds)) / rate
-        ref = 0.25 * np.sin(2 * np.pi * 997 * t) + 0.125 * np.sin(2 * np.pi * 3301 * t) + 0.06 * np.sin(2 * np.pi * 7919 * t)
-        test = ref + 0.004 * np.sin(2 * np.pi * 5003 * t) + 0.002 * np.sin(2 * np.pi * 211 * t)
-        return ref[:, None].astype(np.float32), test[:, None].astype(np.float32)
-    r44, t44 = tones(44100)
-    r48, t48 = tones(48000)
-    write_wav_rate(tmp_path / "r44.wav", r44, 44100)
-    write_wav_rate(tmp_path / "t44.wav", t44, 44100)
-    write_wav_rate(tmp_path / "r48.wav", r48, 48000)
-    write_wav_rate(tmp_path / "t48.wav", t48, 48000)
-    a = run_cli(tmp_path / "r44.wav", tmp_path / "t44.wav")
-    b = run_cli(tmp_path / "r48.wav", tmp_path / "t48.wav")
-    assert a.returncode == 0 and b.returncode == 0, a.stdout + a.stderr + b.stdout + b.stderr
-    assert abs(float(printed(a)[0]) - float(printed(b)[0])) <= 0.02, (printed(a), printed(b))
+    """a 44.1 kHz pair (which the reference accepts through audioresample): the CLI converts it to 48 kHz and
+    prints what the oracle gives for the same conversion done in numpy; the interpolator itself reproduces
+    band-limited tones to the 16-bit quantisation step; --no-resample refuses the files with exit status 2"""
+    rate = 44100
+    t = np.arange(rate) / rate
+    ref = 0.25 * np.sin(2 * np.pi * 997 * t) + 0.125 * np.sin(2 * np.pi * 3301 * t) + 0.06 * np.sin(2 * np.pi * 7919 * t)
+    test = ref + 0.004 * np.sin(2 * np.pi * 5003 * t) + 0.002 * np.sin(2 * np.pi * 211 * t)
+    ref, test = ref[:, None].astype(np.float32), test[:, None].astype(np.float32)
+    write_wav_rate(tmp_path / "r44.wav", ref, rate)
+    write_wav_rate(tmp_path / "t44.wav", test, rate)
+    r48, t48 = resample_np(quantised(ref, 16, False).astype(np.float64), rate), resample_np(quantised(test, 16, False).astype(np.float64), rate)
+    t2 = np.arange(len(r48)) / 48000.
+    ideal = 0.25 * np.sin(2 * np.pi * 997 * t2) + 0.125 * np.sin(2 * np.pi * 3301 * t2) + 0.06 * np.sin(2 * np.pi * 7919 * t2)
+    assert np.abs(r48[2000:-2000, 0] - ideal[2000:-2000]).max() < 4e-5          # 16-bit step: 3e-5
+    exp = orc.run_pair(0, r48, t48)
+    out = run_cli(tmp_path / "r44.wav", tmp_path / "t44.wav")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert abs(float(printed(out)[0]) - exp["odg"]) <= 2e-3 and abs(float(printed(out)[1]) - exp["di"]) <= 2e-3, (printed(out), exp)
     refuse = run_cli("--no-resample", tmp_path / "r44.wav", tmp_path / "t44.wav")
     assert refuse.returncode == 2 and "48 kHz" in refuse.stderr
