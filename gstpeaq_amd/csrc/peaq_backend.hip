@@ -292,7 +292,7 @@ __device__ __forceinline__ double total_loudness(const BandLane<NB, SLOTS>& bl, 
     if (bl.valid(s)) {
       const int b = bl.band(s);
       const double thr = bt.threshold(b);
-      const double l = bt.loud_factor(b) * (pow_pos(1. - thr + div_fast(thr * exc[s], bt.exc_threshold(b)), 0.23) - 1.);
+      const double l = bt.loud_factor(b) * (be_pow(1. - thr + div_fast(thr * exc[s], bt.exc_threshold(b)), 0.23) - 1.);
       t += fmax(l, 0.);
     }
   }
@@ -312,9 +312,9 @@ __device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, 
       const double sref = thres_fac * mod_ref[s] + s0;
       const double stest = thres_fac * mod_test[s] + s0;
       const double ethres = bt.internal_noise(bl.band(s));
-      const double beta = exp_fast(div_fast(-alpha * (e_test[s] - e_ref[s]), e_ref[s]));
-      nl += pow_pos(div_fast(ethres, stest), 0.23) *
-            (pow_pos(1. + div_fast(fmax(stest * e_test[s] - sref * e_ref[s], 0.), ethres + sref * e_ref[s] * beta), 0.23) -
+      const double beta = be_exp(div_fast(-alpha * (e_test[s] - e_ref[s]), e_ref[s]));
+      nl += be_pow(div_fast(ethres, stest), 0.23) *
+            (be_pow(1. + div_fast(fmax(stest * e_test[s] - sref * e_ref[s], 0.), ethres + sref * e_ref[s] * beta), 0.23) -
              1.);
     }
   }
@@ -526,17 +526,17 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
       for (int s = 0; s < SLOTS; ++s) {
         double pc = 0., qc = 0.;
         if (bl.valid(s)) {
-          const double er_db = (10. * kInvLn10) * log_pos(er[s]);     // 10 log10: excitations are > 0
-          const double et_db = (10. * kInvLn10) * log_pos(et[s]);
+          const double er_db = (10. * kInvLn10) * be_log(er[s]);     // 10 log10: excitations are > 0
+          const double et_db = (10. * kInvLn10) * be_log(et[s]);
           const double l = 0.3 * fmax(er_db, et_db) + 0.7 * et_db;
           const double l2 = l * l;
-          const double sd = l > 0. ? 5.95072 * pow_pos(div_fast(6.39468, l), 1.71332) + 9.01033e-11 * l2 * l2 +
+          const double sd = l > 0. ? 5.95072 * be_pow(div_fast(6.39468, l), 1.71332) + 9.01033e-11 * l2 * l2 +
                                          5.05622e-6 * l2 * l - 0.00102438 * l * l + 0.0550197 * l - 0.198719
                                    : 1e30;
           const double e = er_db - et_db;
           const double x = div_fast(e, sd), x2 = x * x;
           const double xb = er_db > et_db ? x2 * x2 : x2 * x2 * x2;   // (e/s)^b, b = 4 or 6
-          pc = 1. - exp_fast(-kLn2 * xb);                             // 1 - 0.5^((e/s)^b)
+          pc = 1. - be_exp(-kLn2 * xb);                             // 1 - 0.5^((e/s)^b)
           qc = div_fast(fabs(trunc(e)), sd);
         }
         sh.pc[chan][bl.band(s)] = pc;

@@ -253,6 +253,30 @@ __device__ __forceinline__ void fir_mfma(BankLds& sh, const double* __restrict__
     const int d = d0 + 4 * s0 + kk;                  // this lane's delay in the first K step
     int u1 = kFbRing - d;                            // window coordinate of x[-d] at t = 0 ...
     int u2 = d - 2;                                  // ... and of its mirror x[-(1458 - d)]
+#ifdef PEAQ_LEDGER_FP32_FIR
+    // Mixed-precision ledger (tools/precision_ledger.py): the FIR bank on the FP32 matrix cores
+    // (v_mfma_f32_16x16x4_f32, twice the FP64 rate) -- an EXPERIMENT to price the precision, never the product.
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f zf = {0.f, 0.f, 0.f, 0.f};
+    v4f fr0 = zf, fr1 = zf, fr2 = zf, fr3 = zf, fi0 = zf, fi1 = zf, fi2 = zf, fi3 = zf;
+    auto step = [&](double hr, double hi) {
+      const double* p1 = sh.win + win_off(u1) + j;
+      const double* p2 = sh.win + win_off(u2) + j;
+      const double x0 = lds_rd(p1), x1 = lds_rd(p1 + 16), x2 = lds_rd(p1 + 32), x3 = lds_rd(p1 + 48);
+      const double y0 = lds_rd(p2), y1 = lds_rd(p2 + 16), y2 = lds_rd(p2 + 32), y3 = lds_rd(p2 + 48);
+      const float hrf = (float)hr, hif = (float)hi;
+      fr0 = __builtin_amdgcn_mfma_f32_16x16x4f32(hrf, (float)x0 + (float)y0, fr0, 0, 0, 0);
+      fi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(hif, (float)x0 - (float)y0, fi0, 0, 0, 0);
+      fr1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hrf, (float)x1 + (float)y1, fr1, 0, 0, 0);
+      fi1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hif, (float)x1 - (float)y1, fi1, 0, 0, 0);
+      fr2 = __builtin_amdgcn_mfma_f32_16x16x4f32(hrf, (float)x2 + (float)y2, fr2, 0, 0, 0);
+      fi2 = __builtin_amdgcn_mfma_f32_16x16x4f32(hif, (float)x2 - (float)y2, fi2, 0, 0, 0);
+      fr3 = __builtin_amdgcn_mfma_f32_16x16x4f32(hrf, (float)x3 + (float)y3, fr3, 0, 0, 0);
+      fi3 = __builtin_amdgcn_mfma_f32_16x16x4f32(hif, (float)x3 - (float)y3, fi3, 0, 0, 0);
+      u1 -= 4;
+      u2 += 4;
+    };
+#else
     auto step = [&](double hr, double hi) {
       const double* p1 = sh.win + win_off(u1) + j;   // time points j, 16 + j, 32 + j, 48 + j
       const double* p2 = sh.win + win_off(u2) + j;
@@ -269,6 +293,7 @@ __device__ __forceinline__ void fir_mfma(BankLds& sh, const double* __restrict__
       u1 -= 4;
       u2 += 4;
     };
+#endif
     // coefficients are requested four K steps (2048 MFMA cycles) ahead of their use
     int s = 0;
     double nr[4], ni[4];
@@ -298,10 +323,25 @@ __device__ __forceinline__ void fir_mfma(BankLds& sh, const double* __restrict__
     }
     for (; s < n; ++s) step(cr[64 * s], ci[64 * s]);
     // D layout: column = lane & 15 (time), row = (lane >> 4) + 4 i  ->  band 16 r + row
+#ifdef PEAQ_LEDGER_FP32_FIR
+    const v4f fr[4] = {fr0, fr1, fr2, fr3}, fi[4] = {fi0, fi1, fi2, fi3};
+    v4d accr[4], acci[4];
+    for (int nt = 0; nt < 4; ++nt)
+      for (int i = 0; i < 4; ++i) {
+        accr[nt][i] = (double)fr[nt][i];
+        acci[nt][i] = (double)fi[nt][i];
+      }
+    (void)ar0; (void)ar1; (void)ar2; (void)ar3; (void)ai0; (void)ai1; (void)ai2; (void)ai3;
+#else
     const v4d accr[4] = {ar0, ar1, ar2, ar3}, acci[4] = {ai0, ai1, ai2, ai3};
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+#ifdef PEAQ_LEDGER_FP32_FIR
+      const int b = 16 * r + 4 * kk + i;               // the FP32 instruction's D layout: row = 4 (lane >> 4) + i
+#else
       const int b = 16 * r + kk + 4 * i;
+#endif
       if (b < kFbBands) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {

@@ -332,6 +332,19 @@ constexpr double kLn2 = 0.69314718055994530942;       // 2^x = e^(x ln 2)
 // ranges of this model.
 __device__ __forceinline__ double pow_pos(double x, double y) { return exp_fast(y * log_pos(x)); }
 
+// Mixed-precision ledger (tools/precision_ledger.py): -DPEAQ_LEDGER_FP32_BACKEND builds
+// evaluate the back end's loudness / detection transcendentals in FP32 -- an EXPERIMENT to price the
+// precision, never the product.
+#ifdef PEAQ_LEDGER_FP32_BACKEND
+__device__ __forceinline__ double be_pow(double x, double y) { return (double)__powf((float)x, (float)y); }
+__device__ __forceinline__ double be_log(double x) { return (double)__logf((float)x); }
+__device__ __forceinline__ double be_exp(double x) { return (double)__expf((float)x); }
+#else
+__device__ __forceinline__ double be_pow(double x, double y) { return pow_pos(x, y); }
+__device__ __forceinline__ double be_log(double x) { return log_pos(x); }
+__device__ __forceinline__ double be_exp(double x) { return exp_fast(x); }
+#endif
+
 // LDS traffic of ONE wave is executed in program order by the hardware; this
 // only stops the compiler from moving LDS accesses across the point.
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }

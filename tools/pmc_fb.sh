@@ -5,7 +5,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS_ATOMIC SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d /tmp/pmcfb$i -o r -- python $R/bench.py --advanced --pairs 1024 --steps 1 --warmup 0 --no-cpu-baseline > $O/pmcfb$i.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmcfb$i -o r -- python $R/bench.py --advanced --pairs 1024 --steps 1 --warmup 0 --no-cpu-baseline > $O/pmcfb$i.log 2>&1
   dbs="$dbs /tmp/pmcfb$i/r_results.db"
 done
 python $R/tools/rocprof_summary.py pmc $dbs > $O/pmc_fb.json

@@ -2,6 +2,6 @@ R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; cd /tmp; export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VMEM_WR"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/pmcset$i -o r01 -- python $R/bench.py --pairs 1024 --steps 1 --warmup 0 --no-cpu-baseline $EXTRA > $R/gpurun_out/pmcset$i.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/pmcset$i -o r01 -- python $R/bench.py --pairs 1024 --steps 1 --warmup 0 --no-cpu-baseline --no-advanced $EXTRA > $R/gpurun_out/pmcset$i.log 2>&1
 done
 ls $R/gpurun_out
