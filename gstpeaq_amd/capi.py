@@ -76,6 +76,8 @@ def load_library():
     L.peaq_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.peaq_ctx_destroy.argtypes = [vp]
     L.peaq_ctx_device.argtypes = [vp]
+    L.peaq_ctx_set_fir_fp64.argtypes = [vp, C.c_int]
+    L.peaq_ctx_get_fir_fp64.argtypes = [vp]
     L.peaq_session_create.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.POINTER(vp)]
     L.peaq_session_destroy.argtypes = [vp]
     L.peaq_session_push.argtypes = [vp, C.c_int, fp, C.c_size_t]
@@ -140,6 +142,13 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_fir_fp64(self, enable):
+        """advanced version: FIR bank on the FP64 matrix instruction (default: FP32, see include/peaq_amd.h)"""
+        _check(self.L.peaq_ctx_set_fir_fp64(self.h, int(bool(enable))))
+
+    def fir_fp64(self):
+        return bool(self.L.peaq_ctx_get_fir_fp64(self.h))
 
     def last_timing(self):
         t = _Timing()

@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -126,6 +127,7 @@ struct peaq_ctx {
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
   unsigned long long* d_prof = nullptr;   // -DPEAQ_FE_PROFILE builds only
+  int fir_fp64 = 0;                       // advanced version: FIR bank on the FP64 instead of the FP32 matrix instruction
 
   hipEvent_t next_event() {
     if (events_used == event_pool.size()) {
@@ -149,6 +151,10 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
   peaq_ctx* c = new (std::nothrow) peaq_ctx;
   if (!c) return fail(PEAQ_ERR_NOMEM, "out of host memory");
   c->device = device;
+  {
+    const char* e = std::getenv("PEAQ_AMD_FIR_FP64");
+    c->fir_fp64 = e && *e && *e != '0';
+  }
   const int rc = [&]() -> int {
   {
     std::vector<CommonTables> h(1);
@@ -228,6 +234,14 @@ extern "C" void peaq_ctx_destroy(peaq_ctx* c) {
 
 extern "C" int peaq_ctx_device(const peaq_ctx* c) { return c ? c->device : -1; }
 
+extern "C" int peaq_ctx_set_fir_fp64(peaq_ctx* c, int enable) {
+  if (!c) return fail(PEAQ_ERR_ARG, "peaq_ctx_set_fir_fp64: ctx is NULL");
+  std::lock_guard<std::mutex> lock(c->mu);
+  c->fir_fp64 = enable ? 1 : 0;
+  return PEAQ_OK;
+}
+extern "C" int peaq_ctx_get_fir_fp64(const peaq_ctx* c) { return c ? c->fir_fp64 : -1; }
+
 #ifdef PEAQ_FE_PROFILE
 // development builds only: reads and clears the front end's phase counters (tools/fe_profile.py)
 extern "C" int peaq_debug_frontend_profile(peaq_ctx* c, unsigned long long* out64) {
@@ -301,6 +315,7 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
     HIP_TRY(c->fbstate.reserve((size_t)n_signals * sizeof(FbSignalState)));
     HIP_TRY(hipMemsetAsync(c->fbstate.p, 0, (size_t)n_signals * sizeof(FbSignalState), stream));
     FbFrontArgs ff{};
+    ff.fir_fp64 = c->fir_fp64;
     ff.ref = d_ref;
     ff.test = d_test;
     ff.pair_stride = pair_stride;
@@ -641,6 +656,7 @@ extern "C" int peaq_debug_filterbank(peaq_ctx* c, int channels, double level_db,
   HIP_TRY(st.reserve(n_signals * sizeof(FbSignalState)));
   HIP_TRY(hipMemset(st.p, 0, n_signals * sizeof(FbSignalState)));
   FbFrontArgs ff{};
+  ff.fir_fp64 = c->fir_fp64;
   ff.ref = d_ref;
   ff.test = d_test;
   ff.pair_stride = std::max(n_ref, n_test);
@@ -896,6 +912,7 @@ static int session_run_blocks(peaq_session* s, unsigned nb, const uint64_t n_val
     if (rc != PEAQ_OK) return rc;
   }
   FbFrontArgs ff{};
+  ff.fir_fp64 = c->fir_fp64;
   ff.ref = s->d_sig[0].as<float>();
   ff.test = s->d_sig[1].as<float>();
   ff.pair_stride = s->stage_samples;
@@ -1288,6 +1305,7 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
                              b->stream));
     HIP_TRY(hipMemcpyAsync(b->d_win.p, b->h_win, fb_active * sizeof(FbPairWindow), hipMemcpyHostToDevice, b->stream));
     FbFrontArgs ff{};
+    ff.fir_fp64 = c->fir_fp64;
     ff.ref = b->fbs.d[0].as<float>();
     ff.test = b->fbs.d[1].as<float>();
     ff.pair_stride = b->fbs.samples;

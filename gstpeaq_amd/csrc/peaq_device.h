@@ -86,6 +86,8 @@ struct FbTables {               // fbearmodel.c:57-61,182-225
   // the centre tap carries half its weight (its two "mirror" samples coincide)
   double mf_re[kMfTotalSteps * 64];
   double mf_im[kMfTotalSteps * 64];
+  float  mf_re_f[kMfTotalSteps * 64];   // the same, rounded, for the FP32 matrix instruction
+  float  mf_im_f[kMfTotalSteps * 64];
 };
 
 // ---- per-frame record: front end -> back end --------------------------------

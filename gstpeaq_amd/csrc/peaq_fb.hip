@@ -197,8 +197,11 @@ constexpr int kACols = 64;                          // A[band][time] row stride
 // column u div 32 -- lanes (time points 32 samples apart) then sit in consecutive columns
 __host__ __device__ constexpr int win_off(int u) { return (u & 31) * kWinRow + (u >> 5); }
 
+// WT = the type the FIR phase computes in: double (v_mfma_f64_16x16x4_f64) or float
+// (v_mfma_f32_16x16x4_f32, twice the rate; see fir_mfma).  Everything after the FIR is FP64 either way.
+template <typename WT>
 struct BankLds {
-  double win[32 * kWinRow];                         // phase 1: the filtered signal, B operand of the GEMM
+  WT win[32 * kWinRow];                             // phase 1: the filtered signal, B operand of the GEMM
   struct {
     double re[kFbBands][kACols];                    // A[band][time]: GEMM result, then phases 2..4 in place
     double im[kFbBands][kACols];
@@ -213,6 +216,9 @@ struct BankLds {
 // only 128 (MI355X_MICROARCH.md, LDS table): volatile accesses keep every read its own ds_read_b64.
 __device__ __forceinline__ double lds_rd(const double* p) {
   return *(const volatile __attribute__((address_space(3))) double*)p;
+}
+__device__ __forceinline__ float lds_rd(const float* p) {
+  return *(const volatile __attribute__((address_space(3))) float*)p;
 }
 
 // ---------------------------------------------------------------------------
@@ -231,9 +237,32 @@ __device__ __forceinline__ double lds_rd(const double* p) {
 // actually kept full and the VALU stays free for the operand construction.
 // ---------------------------------------------------------------------------
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void fir_mfma(BankLds& sh, const double* __restrict__ mf_re,
-                                         const double* __restrict__ mf_im, int wv, int lane) {
+// the two matrix instructions behind one interface; ROW(lane >> 4, i) = row of accumulator element i
+struct MfmaF64 {
+  typedef double T;
+  typedef v4d Acc;
+  static __device__ __forceinline__ Acc mma(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int kk, int i) { return kk + 4 * i; }
+};
+struct MfmaF32 {
+  typedef float T;
+  typedef v4f Acc;
+  static __device__ __forceinline__ Acc mma(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int kk, int i) { return 4 * kk + i; }
+};
+
+// FP32 variant: the mixed-precision ledger (tools/precision_ledger.py, profiles/r02_precision_ledger.json)
+// prices it at max |dODG| = 5e-8 over 39 advanced cases -- the FIR outputs only enter the model as
+// |A|^2 in 40 bands after spreading and masking -- for twice the matrix rate, half the LDS traffic of the
+// window and FP32 operand construction.  The engine therefore runs it by default; peaq_ctx_set_fir_fp64()
+// or PEAQ_AMD_FIR_FP64=1 selects the FP64 instruction (the stage tests hold THAT to 1e-9 of the oracle).
+template <typename M>
+__device__ __forceinline__ void fir_mfma(BankLds<typename M::T>& sh, const typename M::T* __restrict__ mf_re,
+                                         const typename M::T* __restrict__ mf_im, int wv, int lane) {
+  typedef typename M::T T;
+  typedef typename M::Acc Acc;
   const int j = lane & 15, kk = lane >> 4;
   // K steps [g, g_end) of this wave: 66 + 65 + 65 + 65
   int g = wv == 0 ? 0 : 1 + 65 * wv;
@@ -246,57 +275,32 @@ __device__ __forceinline__ void fir_mfma(BankLds& sh, const double* __restrict__
     const int d0 = r == 2 ? kMfD0[2] : r == 1 ? kMfD0[1] : kMfD0[0];
     const int s0 = g - base;
     const int n = min(steps - s0, g_end - g);        // K steps of this segment
-    const v4d zero = {0., 0., 0., 0.};
-    v4d ar0 = zero, ar1 = zero, ar2 = zero, ar3 = zero, ai0 = zero, ai1 = zero, ai2 = zero, ai3 = zero;
-    const double* __restrict__ cr = mf_re + (size_t)g * 64 + lane;
-    const double* __restrict__ ci = mf_im + (size_t)g * 64 + lane;
+    const Acc zero = {0, 0, 0, 0};
+    Acc ar0 = zero, ar1 = zero, ar2 = zero, ar3 = zero, ai0 = zero, ai1 = zero, ai2 = zero, ai3 = zero;
+    const T* __restrict__ cr = mf_re + (size_t)g * 64 + lane;
+    const T* __restrict__ ci = mf_im + (size_t)g * 64 + lane;
     const int d = d0 + 4 * s0 + kk;                  // this lane's delay in the first K step
     int u1 = kFbRing - d;                            // window coordinate of x[-d] at t = 0 ...
     int u2 = d - 2;                                  // ... and of its mirror x[-(1458 - d)]
-#ifdef PEAQ_LEDGER_FP32_FIR
-    // Mixed-precision ledger (tools/precision_ledger.py): the FIR bank on the FP32 matrix cores
-    // (v_mfma_f32_16x16x4_f32, twice the FP64 rate) -- an EXPERIMENT to price the precision, never the product.
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f zf = {0.f, 0.f, 0.f, 0.f};
-    v4f fr0 = zf, fr1 = zf, fr2 = zf, fr3 = zf, fi0 = zf, fi1 = zf, fi2 = zf, fi3 = zf;
-    auto step = [&](double hr, double hi) {
-      const double* p1 = sh.win + win_off(u1) + j;
-      const double* p2 = sh.win + win_off(u2) + j;
-      const double x0 = lds_rd(p1), x1 = lds_rd(p1 + 16), x2 = lds_rd(p1 + 32), x3 = lds_rd(p1 + 48);
-      const double y0 = lds_rd(p2), y1 = lds_rd(p2 + 16), y2 = lds_rd(p2 + 32), y3 = lds_rd(p2 + 48);
-      const float hrf = (float)hr, hif = (float)hi;
-      fr0 = __builtin_amdgcn_mfma_f32_16x16x4f32(hrf, (float)x0 + (float)y0, fr0, 0, 0, 0);
-      fi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(hif, (float)x0 - (float)y0, fi0, 0, 0, 0);
-      fr1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hrf, (float)x1 + (float)y1, fr1, 0, 0, 0);
-      fi1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hif, (float)x1 - (float)y1, fi1, 0, 0, 0);
-      fr2 = __builtin_amdgcn_mfma_f32_16x16x4f32(hrf, (float)x2 + (float)y2, fr2, 0, 0, 0);
-      fi2 = __builtin_amdgcn_mfma_f32_16x16x4f32(hif, (float)x2 - (float)y2, fi2, 0, 0, 0);
-      fr3 = __builtin_amdgcn_mfma_f32_16x16x4f32(hrf, (float)x3 + (float)y3, fr3, 0, 0, 0);
-      fi3 = __builtin_amdgcn_mfma_f32_16x16x4f32(hif, (float)x3 - (float)y3, fi3, 0, 0, 0);
+    auto step = [&](T hr, T hi) {
+      const T* p1 = sh.win + win_off(u1) + j;        // time points j, 16 + j, 32 + j, 48 + j
+      const T* p2 = sh.win + win_off(u2) + j;
+      const T x0 = lds_rd(p1), x1 = lds_rd(p1 + 16), x2 = lds_rd(p1 + 32), x3 = lds_rd(p1 + 48);
+      const T y0 = lds_rd(p2), y1 = lds_rd(p2 + 16), y2 = lds_rd(p2 + 32), y3 = lds_rd(p2 + 48);
+      ar0 = M::mma(hr, x0 + y0, ar0);
+      ai0 = M::mma(hi, x0 - y0, ai0);
+      ar1 = M::mma(hr, x1 + y1, ar1);
+      ai1 = M::mma(hi, x1 - y1, ai1);
+      ar2 = M::mma(hr, x2 + y2, ar2);
+      ai2 = M::mma(hi, x2 - y2, ai2);
+      ar3 = M::mma(hr, x3 + y3, ar3);
+      ai3 = M::mma(hi, x3 - y3, ai3);
       u1 -= 4;
       u2 += 4;
     };
-#else
-    auto step = [&](double hr, double hi) {
-      const double* p1 = sh.win + win_off(u1) + j;   // time points j, 16 + j, 32 + j, 48 + j
-      const double* p2 = sh.win + win_off(u2) + j;
-      const double x0 = lds_rd(p1), x1 = lds_rd(p1 + 16), x2 = lds_rd(p1 + 32), x3 = lds_rd(p1 + 48);
-      const double y0 = lds_rd(p2), y1 = lds_rd(p2 + 16), y2 = lds_rd(p2 + 32), y3 = lds_rd(p2 + 48);
-      ar0 = __builtin_amdgcn_mfma_f64_16x16x4f64(hr, x0 + y0, ar0, 0, 0, 0);
-      ai0 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, x0 - y0, ai0, 0, 0, 0);
-      ar1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hr, x1 + y1, ar1, 0, 0, 0);
-      ai1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, x1 - y1, ai1, 0, 0, 0);
-      ar2 = __builtin_amdgcn_mfma_f64_16x16x4f64(hr, x2 + y2, ar2, 0, 0, 0);
-      ai2 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, x2 - y2, ai2, 0, 0, 0);
-      ar3 = __builtin_amdgcn_mfma_f64_16x16x4f64(hr, x3 + y3, ar3, 0, 0, 0);
-      ai3 = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, x3 - y3, ai3, 0, 0, 0);
-      u1 -= 4;
-      u2 += 4;
-    };
-#endif
-    // coefficients are requested four K steps (2048 MFMA cycles) ahead of their use
+    // coefficients are requested four K steps ahead of their use
     int s = 0;
-    double nr[4], ni[4];
+    T nr[4], ni[4];
     if (n >= 4) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -305,7 +309,7 @@ __device__ __forceinline__ void fir_mfma(BankLds& sh, const double* __restrict__
       }
     }
     for (; s + 4 <= n; s += 4) {
-      double kr[4], ki[4];
+      T kr[4], ki[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         kr[q] = nr[q];
@@ -322,31 +326,16 @@ __device__ __forceinline__ void fir_mfma(BankLds& sh, const double* __restrict__
       for (int q = 0; q < 4; ++q) step(kr[q], ki[q]);
     }
     for (; s < n; ++s) step(cr[64 * s], ci[64 * s]);
-    // D layout: column = lane & 15 (time), row = (lane >> 4) + 4 i  ->  band 16 r + row
-#ifdef PEAQ_LEDGER_FP32_FIR
-    const v4f fr[4] = {fr0, fr1, fr2, fr3}, fi[4] = {fi0, fi1, fi2, fi3};
-    v4d accr[4], acci[4];
-    for (int nt = 0; nt < 4; ++nt)
-      for (int i = 0; i < 4; ++i) {
-        accr[nt][i] = (double)fr[nt][i];
-        acci[nt][i] = (double)fi[nt][i];
-      }
-    (void)ar0; (void)ar1; (void)ar2; (void)ar3; (void)ai0; (void)ai1; (void)ai2; (void)ai3;
-#else
-    const v4d accr[4] = {ar0, ar1, ar2, ar3}, acci[4] = {ai0, ai1, ai2, ai3};
-#endif
+    // D layout: column = lane & 15 (time), row = M::row(lane >> 4, i)  ->  band 16 r + row
+    const Acc accr[4] = {ar0, ar1, ar2, ar3}, acci[4] = {ai0, ai1, ai2, ai3};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-#ifdef PEAQ_LEDGER_FP32_FIR
-      const int b = 16 * r + 4 * kk + i;               // the FP32 instruction's D layout: row = 4 (lane >> 4) + i
-#else
-      const int b = 16 * r + kk + 4 * i;
-#endif
+      const int b = 16 * r + M::row(kk, i);
       if (b < kFbBands) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          atomicAdd(&sh.a.re[b][16 * nt + j], accr[nt][i]);
-          atomicAdd(&sh.a.im[b][16 * nt + j], acci[nt][i]);
+          atomicAdd(&sh.a.re[b][16 * nt + j], (double)accr[nt][i]);
+          atomicAdd(&sh.a.im[b][16 * nt + j], (double)acci[nt][i]);
         }
       }
     }
@@ -360,8 +349,8 @@ __host__ __device__ constexpr int wave_band(int w, int i) { return (i & 1) ? 8 *
 // upward spreading of wave W's ten source bands (ascending: wave_band(W, 0) < ... < wave_band(W, 9)):
 // target band j receives sum_{sources b < j} A[b] cu_b^(j-b); everything about the band indices
 // is a compile-time constant, the code is a straight line of multiplies, adds and 78 atomics
-template <int W>
-__device__ __forceinline__ void spread_up(BankLds& sh, const double (&re)[10], const double (&im)[10],
+template <int W, typename WT>
+__device__ __forceinline__ void spread_up(BankLds<WT>& sh, const double (&re)[10], const double (&im)[10],
                                           const double (&cu)[10], int lane) {
   double tr[10], ti[10];
 #pragma unroll
@@ -390,8 +379,10 @@ __device__ __forceinline__ void spread_up(BankLds& sh, const double (&re)[10], c
   }
 }
 
+template <typename M>
 __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned n_signals) {
-  __shared__ BankLds sh;
+  typedef typename M::T WT;
+  __shared__ BankLds<WT> sh;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: say so
@@ -458,12 +449,12 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
     // requested a whole tile ago (see below phase 2a) -------------------------------------------------
     if (b0 == 0) {
       const int avail = (int)min((size_t)kWin, row_valid);
-      for (int wdx = tid; wdx < kWin; wdx += 256) sh.win[win_off(wdx)] = wdx < avail ? row[wdx] : 0.;
+      for (int wdx = tid; wdx < kWin; wdx += 256) sh.win[win_off(wdx)] = wdx < avail ? (WT)row[wdx] : (WT)0;
     } else {
 #pragma unroll
       for (int q = 0; q < kPre; ++q) {
         const int wdx = kKeep + tid + 256 * q;
-        if (wdx < kWin) sh.win[win_off(wdx)] = pre[q];
+        if (wdx < kWin) sh.win[win_off(wdx)] = (WT)pre[q];
       }
     }
     {
@@ -472,7 +463,10 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
     }
     __syncthreads();
     // ---- phase 1: the complex FIR filters (fbearmodel.c:399-435) as a GEMM on the matrix cores ---
-    fir_mfma(sh, fb->mf_re, fb->mf_im, wv, lane);
+    if (sizeof(WT) == 8)
+      fir_mfma<M>(sh, reinterpret_cast<const WT*>(fb->mf_re), reinterpret_cast<const WT*>(fb->mf_im), wv, lane);
+    else
+      fir_mfma<M>(sh, reinterpret_cast<const WT*>(fb->mf_re_f), reinterpret_cast<const WT*>(fb->mf_im_f), wv, lane);
     __syncthreads();                                                 // A is complete
     // ---- phase 2a: every wave picks up its ten bands at its time point ---------------------------
     double re[10], im[10];
@@ -486,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       // band 0 (= re[0] of wave 0): its tap at delay 1456 reads the NEWEST sample in the reference
       // (the doubled ring buffer makes fb_buf[offset + 1456] alias fb_buf[offset], fbearmodel.c:413-414)
       const int tt = lane < kTileSub ? lane : kTileSub - 1;
-      const double delta = sh.win[win_off(kFbRing) + tt] - sh.win[win_off(0) + tt];
+      const double delta = (double)sh.win[win_off(kFbRing) + tt] - (double)sh.win[win_off(0) + tt];
       re[0] = fma(fb->h_re[1], delta, re[0]);
       im[0] = fma(-fb->h_im[1], delta, im[0]);
       sh.a.re[0][lane] = re[0];                      // band 0 is nobody's spreading target
@@ -530,10 +524,10 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       cuv[i] = cu;
     }
     switch (wv) {
-      case 0: spread_up<0>(sh, re, im, cuv, lane); break;
-      case 1: spread_up<1>(sh, re, im, cuv, lane); break;
-      case 2: spread_up<2>(sh, re, im, cuv, lane); break;
-      default: spread_up<3>(sh, re, im, cuv, lane); break;
+      case 0: spread_up<0, WT>(sh, re, im, cuv, lane); break;
+      case 1: spread_up<1, WT>(sh, re, im, cuv, lane); break;
+      case 2: spread_up<2, WT>(sh, re, im, cuv, lane); break;
+      default: spread_up<3, WT>(sh, re, im, cuv, lane); break;
     }
     __syncthreads();
     // ---- phase 3: downward spreading (fbearmodel.c:351-354): wave 0 the real, wave 1 the
@@ -627,7 +621,10 @@ hipError_t launch_fb_hp(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stre
 hipError_t launch_fb_bank(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream) {
   const unsigned n_signals = n_pairs * a.channels * 2;
   if (n_signals == 0 || a.blocks_per_launch == 0) return hipSuccess;
-  hipLaunchKernelGGL(fb_bank_kernel, dim3(n_signals), dim3(256), 0, stream, a, n_signals);
+  if (a.fir_fp64)
+    hipLaunchKernelGGL(fb_bank_kernel<MfmaF64>, dim3(n_signals), dim3(256), 0, stream, a, n_signals);
+  else
+    hipLaunchKernelGGL(fb_bank_kernel<MfmaF32>, dim3(n_signals), dim3(256), 0, stream, a, n_signals);
   return hipGetLastError();
 }
 

@@ -102,6 +102,7 @@ struct FbFrontArgs {
   size_t hp_row_stride;
   double* records;              // [pair][block - block0][channel][kFbRecDoubles]
   const FbPairWindow* windows;  // broker launches (see above); nullptr: the uniform fields apply, slot = pair
+  int fir_fp64;                 // 1: FIR bank on v_mfma_f64 (exact to the oracle's 1e-9); 0: v_mfma_f32 (default, see peaq_fb.hip)
 };
 hipError_t launch_fb_frontend(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream);   // high-pass + filter bank
 hipError_t launch_fb_hp(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream);

@@ -191,6 +191,8 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
         }
         fb.mf_re[(size_t)(kMfBase[r] + s) * 64 + lane] = vr;
         fb.mf_im[(size_t)(kMfBase[r] + s) * 64 + lane] = vi;
+        fb.mf_re_f[(size_t)(kMfBase[r] + s) * 64 + lane] = (float)vr;
+        fb.mf_im_f[(size_t)(kMfBase[r] + s) * 64 + lane] = (float)vi;
       }
   }
   for (int k = 0; k < 6; ++k) {

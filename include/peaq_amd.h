@@ -69,6 +69,15 @@ typedef struct peaq_ctx peaq_ctx;
 int peaq_ctx_create (int device_ordinal, peaq_ctx **out);
 void peaq_ctx_destroy (peaq_ctx *ctx);
 int peaq_ctx_device (const peaq_ctx *ctx);
+/* Advanced version only: which matrix instruction evaluates the 40 complex FIR filters of the
+ * filter-bank ear model (fbearmodel.c:399-435).  Default 0 = FP32 (v_mfma_f32_16x16x4_f32, twice the
+ * rate): measured max |dODG| against the all-FP64 path 5e-8 over 39 advanced cases
+ * (profiles/r02_precision_ledger.json).  1 = FP64 (v_mfma_f64_16x16x4_f64), which follows the
+ * reference's double arithmetic to 1e-9 per block; also selected by the environment variable
+ * PEAQ_AMD_FIR_FP64=1 at context creation.  Everything else is FP64 either way.  Applies to the
+ * launches that follow. */
+int peaq_ctx_set_fir_fp64 (peaq_ctx *ctx, int enable);
+int peaq_ctx_get_fir_fp64 (const peaq_ctx *ctx);
 
 /* ---- session API ------------------------------------------------------------
  * Replaces, per element instance: g_object_new(PEAQ_TYPE_FFTEARMODEL /

@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""Mixed-precision ledger (report only, the product stays FP64).
+"""Mixed-precision ledger: what does FP32 cost in ODG, part by part?
 
-For experimental builds of the engine in which one part of the arithmetic runs in FP32
-  make -C gstpeaq_amd/csrc VARIANT=fp32fir EXTRA=-DPEAQ_LEDGER_FP32_FIR       FIR bank on the FP32 matrix cores
-  make -C gstpeaq_amd/csrc VARIANT=fp32be  EXTRA=-DPEAQ_LEDGER_FP32_BACKEND   back-end loudness / detection pow, log, exp
-this tool runs every end-to-end golden case of tests/golden/ref_e2e.json (62 cases with the level cases, basic
-and advanced) and 8 full-size seeded pairs (10 s stereo) through the product library and through each variant,
-and tabulates max |dODG|, max |dDI| and the per-MOV max relative deviation of the variant from the FP64 path.
+The baseline is the engine with everything in FP64 (PEAQ_AMD_FIR_FP64=1).  Compared with it:
+  * the engine's default, in which the filter bank's FIR filters run on the FP32 matrix instruction
+    (peaq_fb.hip, fir_mfma<MfmaF32>) -- this table is the evidence behind that default;
+  * an experimental build with the back end's loudness / detection pow, log, exp in FP32 (report only):
+      make -C gstpeaq_amd/csrc VARIANT=fp32be EXTRA=-DPEAQ_LEDGER_FP32_BACKEND
+Every end-to-end golden case of tests/golden/ref_e2e*.json (62 cases, basic and advanced) and 8 full-size
+seeded pairs (10 s stereo) per version go through each configuration; tabulated are max |dODG|, max |dDI| and
+the per-MOV max relative deviation from the all-FP64 baseline (with the case it occurs in).
 
-  python tools/precision_ledger.py [--out profiles/r02_precision_ledger.json] name=path/to/lib.so ...
-(the worker mode `--dump LIB` is internal: one process per library, PEAQ_AMD_LIB selects it)."""
+  python tools/precision_ledger.py [--out profiles/r02_precision_ledger.json] ["name=lib.so[,ENV=VALUE]" ...]
+(the worker mode `--dump` is internal: one process per configuration)."""
 import json
 import os
 import subprocess
@@ -62,14 +64,19 @@ def main():
     if args and args[0] == "--out":
         out_path = Path(args[1])
         args = args[2:]
-    libs = {"fp64 (product)": None}
+    libs = {"all FP64 (baseline)": ("", {"PEAQ_AMD_FIR_FP64": "1"}),
+            "engine default: FIR bank on v_mfma_f32_16x16x4_f32": ("", {}),
+            "all FP64 again (run-to-run variation)": ("", {"PEAQ_AMD_FIR_FP64": "1"})}
     for a in args:
-        name, path = a.split("=", 1)
-        libs[name] = str(Path(path).resolve())
+        name, spec = a.split("=", 1)
+        parts = spec.split(",")
+        libs[name] = (str(Path(parts[0]).resolve()) if parts[0] else "", dict(p.split("=", 1) for p in parts[1:]))
     results = {}
-    for name, path in libs.items():
+    for name, (path, extra_env) in libs.items():
         env = dict(os.environ)
         env.pop("PEAQ_AMD_LIB", None)
+        env.pop("PEAQ_AMD_FIR_FP64", None)
+        env.update(extra_env)
         if path:
             env["PEAQ_AMD_LIB"] = path
         o = subprocess.run([sys.executable, __file__, "--dump"], capture_output=True, text=True, env=env, timeout=900)
@@ -77,16 +84,17 @@ def main():
             raise SystemExit(f"{name}: {o.stderr[-2000:]}")
         results[name] = json.loads(o.stdout.strip().splitlines()[-1])
     from gstpeaq_amd.capi import MOV_NAMES_ADVANCED, MOV_NAMES_BASIC
-    base = results["fp64 (product)"]
+    base = results["all FP64 (baseline)"]
     ledger = {"_what": __doc__.split("\n\n")[0], "cases": len(base)}
     for name, res in results.items():
-        if name == "fp64 (product)":
+        if name == "all FP64 (baseline)":
             continue
         entry = {}
         for adv, label, names in ((0, "basic", MOV_NAMES_BASIC), (1, "advanced", MOV_NAMES_ADVANCED)):
             d_odg = d_di = 0.0
             worst = None
             mov = {n: 0.0 for n in names}
+            mov_where = {n: None for n in names}
             nan_mismatch = 0
             for b, v in zip(base, res):
                 if b["advanced"] != adv:
@@ -99,9 +107,11 @@ def main():
                 d_di = max(d_di, abs(b["di"] - v["di"]))
                 for n, x, y in zip(names, b["movs"], v["movs"]):
                     if not (np.isnan(x) or np.isnan(y)):
-                        mov[n] = max(mov[n], abs(x - y) / max(abs(x), abs(y), 1e-12))
+                        rel = abs(x - y) / max(abs(x), abs(y), 1e-12)
+                        if rel > mov[n]:
+                            mov[n], mov_where[n] = rel, dict(case=b["name"], fp64=x, variant=y)
             entry[label] = dict(max_abs_dODG=d_odg, worst_case=worst, max_abs_dDI=d_di, mov_max_rel=mov,
-                                nan_mismatches=nan_mismatch)
+                                mov_max_rel_where=mov_where, nan_mismatches=nan_mismatch)
         ledger[name] = entry
     out_path.write_text(json.dumps(ledger, indent=1) + "\n")
     print(json.dumps(ledger, indent=1))
