@@ -261,7 +261,6 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
 // the flush frame (gstpeaq.c:733-738) costs nothing and there is only one load path (gfx950
 // checks the range of a multi-dword buffer load dword by dword, and dword alignment is enough).
 // ---------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct FrameSrc {
@@ -286,9 +285,11 @@ struct FrameSrc {
       x0 = __uint_as_float(v.x);
       x1 = __uint_as_float(v.y);
     } else {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, n * 16, 0, 0);
-      x0 = __uint_as_float(chan ? v.y : v.x);
-      x1 = __uint_as_float(chan ? v.w : v.z);
+      // two 4-byte loads of this channel rather than 16 bytes of both: half the data through the
+      // return path of the vector-memory pipe (its busiest part), no selects, and the sibling
+      // channel's workgroup finds the lines in L2 either way (+2 % measured)
+      x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, n * 16 + chan * 4, 0, 0));
+      x1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, n * 16 + chan * 4 + 8, 0, 0));
     }
   }
 };
