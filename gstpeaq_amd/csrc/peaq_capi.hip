@@ -305,7 +305,11 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
     const unsigned n_signals = (unsigned)n_pairs * channels * 2;
     const unsigned bc = fb_blocks_per_chunk(n_pairs, channels, max_blocks);
     const size_t row_stride = (size_t)kFbRing + (size_t)bc * kFbFrame;
+#ifdef PEAQ_DEV_SERIAL                                // development: every kernel alone on the device (solo kernel times)
+    const bool piped = false;
+#else
     const bool piped = max_blocks > bc;               // more than one chunk: 3-stage pipeline, double buffers
+#endif
     HIP_TRY(c->hp_scratch.reserve((size_t)n_signals * row_stride * sizeof(double)));
     HIP_TRY(c->fb_records.reserve((size_t)n_pairs * bc * channels * kFbRecDoubles * sizeof(double)));
     if (piped) {
@@ -482,12 +486,17 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
     if (!forked) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(forked, stream));
     HIP_TRY(hipStreamWaitEvent(c->aux2, forked, 0));
+#ifdef PEAQ_DEV_SERIAL
+    hipStream_t s_fb = stream;
+#else
+    hipStream_t s_fb = c->aux2;
+#endif
     const int rc = run_filterbank_path(c, channels, level_db, n_pairs, d_ref, d_test, pair_stride, d_nref, d_ntest,
-                                       n_uniform, d_nblocks, max_blocks, c->aux2);
+                                       n_uniform, d_nblocks, max_blocks, s_fb);
     if (rc != PEAQ_OK) return rc;
     fb_done = c->next_event();
     if (!fb_done) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
-    HIP_TRY(hipEventRecord(fb_done, c->aux2));
+    HIP_TRY(hipEventRecord(fb_done, s_fb));
   }
 
   FrontendArgs fa{};

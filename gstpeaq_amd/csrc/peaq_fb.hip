@@ -258,6 +258,39 @@ struct MfmaF32 {
 // |A|^2 in 40 bands after spreading and masking -- for twice the matrix rate, half the LDS traffic of the
 // window and FP32 operand construction.  The engine therefore runs it by default; peaq_ctx_set_fir_fp64()
 // or PEAQ_AMD_FIR_FP64=1 selects the FP64 instruction (the stage tests hold THAT to 1e-9 of the oracle).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Adds the accumulator tiles of one run of K steps into A (LDS atomics; A was zeroed in phase 0).
+// D layout: column = lane & 15 (time), row = M::row(lane >> 4, i)  ->  band 16 r + row
+template <typename M>
+__device__ __forceinline__ void fir_store(BankLds<typename M::T>& sh, int r, int j, int kk,
+                                          const typename M::Acc (&accr)[4], const typename M::Acc (&acci)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = 16 * r + M::row(kk, i);
+    if (b < kFbBands) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        atomicAdd(&sh.a.re[b][16 * nt + j], (double)accr[nt][i]);
+        atomicAdd(&sh.a.im[b][16 * nt + j], (double)acci[nt][i]);
+      }
+    }
+  }
+}
+
+// which row tile a K step belongs to, where the tile starts and how many steps it has
+struct FirSeg {
+  int r, s0, n, d0;
+  __device__ __forceinline__ FirSeg(int g, int g_end) {
+    r = g >= kMfBase[2] ? 2 : g >= kMfBase[1] ? 1 : 0;
+    const int base = r == 2 ? kMfBase[2] : r == 1 ? kMfBase[1] : 0;
+    const int steps = r == 2 ? kMfSteps[2] : r == 1 ? kMfSteps[1] : kMfSteps[0];
+    d0 = r == 2 ? kMfD0[2] : r == 1 ? kMfD0[1] : kMfD0[0];
+    s0 = g - base;
+    n = min(steps - s0, g_end - g);                  // K steps of this segment
+  }
+};
+
 template <typename M>
 __device__ __forceinline__ void fir_mfma(BankLds<typename M::T>& sh, const typename M::T* __restrict__ mf_re,
                                          const typename M::T* __restrict__ mf_im, int wv, int lane) {
@@ -269,34 +302,48 @@ __device__ __forceinline__ void fir_mfma(BankLds<typename M::T>& sh, const typen
   const int g_end = 66 + 65 * wv;
   static_assert(66 + 65 * 3 == kMfTotalSteps, "split of the K steps over the four waves");
   while (g < g_end) {
-    const int r = g >= kMfBase[2] ? 2 : g >= kMfBase[1] ? 1 : 0;
-    const int base = r == 2 ? kMfBase[2] : r == 1 ? kMfBase[1] : 0;
-    const int steps = r == 2 ? kMfSteps[2] : r == 1 ? kMfSteps[1] : kMfSteps[0];
-    const int d0 = r == 2 ? kMfD0[2] : r == 1 ? kMfD0[1] : kMfD0[0];
-    const int s0 = g - base;
-    const int n = min(steps - s0, g_end - g);        // K steps of this segment
+    const FirSeg sg(g, g_end);
+    const int n = sg.n;
     const Acc zero = {0, 0, 0, 0};
     Acc ar0 = zero, ar1 = zero, ar2 = zero, ar3 = zero, ai0 = zero, ai1 = zero, ai2 = zero, ai3 = zero;
     const T* __restrict__ cr = mf_re + (size_t)g * 64 + lane;
     const T* __restrict__ ci = mf_im + (size_t)g * 64 + lane;
-    const int d = d0 + 4 * s0 + kk;                  // this lane's delay in the first K step
+    const int d = sg.d0 + 4 * sg.s0 + kk;            // this lane's delay in the first K step
     int u1 = kFbRing - d;                            // window coordinate of x[-d] at t = 0 ...
     int u2 = d - 2;                                  // ... and of its mirror x[-(1458 - d)]
-    auto step = [&](T hr, T hi) {
+    // the B operands of a K step are read from LDS one step ahead of their use, so that the eight
+    // MFMAs of the step before cover the LDS latency (the read past the end of a run is harmless: the
+    // window has 1456 + 59 * 32 samples, the delays stay below 736)
+    T bx[4], by[4];
+    auto fetch = [&](T (&x)[4], T (&y)[4]) {
       const T* p1 = sh.win + win_off(u1) + j;        // time points j, 16 + j, 32 + j, 48 + j
       const T* p2 = sh.win + win_off(u2) + j;
-      const T x0 = lds_rd(p1), x1 = lds_rd(p1 + 16), x2 = lds_rd(p1 + 32), x3 = lds_rd(p1 + 48);
-      const T y0 = lds_rd(p2), y1 = lds_rd(p2 + 16), y2 = lds_rd(p2 + 32), y3 = lds_rd(p2 + 48);
-      ar0 = M::mma(hr, x0 + y0, ar0);
-      ai0 = M::mma(hi, x0 - y0, ai0);
-      ar1 = M::mma(hr, x1 + y1, ar1);
-      ai1 = M::mma(hi, x1 - y1, ai1);
-      ar2 = M::mma(hr, x2 + y2, ar2);
-      ai2 = M::mma(hi, x2 - y2, ai2);
-      ar3 = M::mma(hr, x3 + y3, ar3);
-      ai3 = M::mma(hi, x3 - y3, ai3);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        x[q] = lds_rd(p1 + 16 * q);
+        y[q] = lds_rd(p2 + 16 * q);
+      }
+    };
+    fetch(bx, by);
+    auto step = [&](T hr, T hi) {
+      T nx[4], ny[4];
       u1 -= 4;
       u2 += 4;
+      fetch(nx, ny);
+      __builtin_amdgcn_sched_barrier(0);             // keep the reads up here (the scheduler sinks them to their use)
+      ar0 = M::mma(hr, bx[0] + by[0], ar0);
+      ai0 = M::mma(hi, bx[0] - by[0], ai0);
+      ar1 = M::mma(hr, bx[1] + by[1], ar1);
+      ai1 = M::mma(hi, bx[1] - by[1], ai1);
+      ar2 = M::mma(hr, bx[2] + by[2], ar2);
+      ai2 = M::mma(hi, bx[2] - by[2], ai2);
+      ar3 = M::mma(hr, bx[3] + by[3], ar3);
+      ai3 = M::mma(hi, bx[3] - by[3], ai3);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bx[q] = nx[q];
+        by[q] = ny[q];
+      }
     };
     // coefficients are requested four K steps ahead of their use
     int s = 0;
@@ -326,19 +373,91 @@ __device__ __forceinline__ void fir_mfma(BankLds<typename M::T>& sh, const typen
       for (int q = 0; q < 4; ++q) step(kr[q], ki[q]);
     }
     for (; s < n; ++s) step(cr[64 * s], ci[64 * s]);
-    // D layout: column = lane & 15 (time), row = M::row(lane >> 4, i)  ->  band 16 r + row
     const Acc accr[4] = {ar0, ar1, ar2, ar3}, acci[4] = {ai0, ai1, ai2, ai3};
+    fir_store<M>(sh, sg.r, j, kk, accr, acci);
+    g += n;
+  }
+}
+
+// The FP32 instruction's loop, trimmed to what the matrix pipe needs per K step: four ds_read2_b32 (two
+// time tiles each), eight packed FP32 adds for the folded operands, two address updates -- the LDS offsets
+// of eight consecutive K steps (32 delays = one window column) are kept per lane and move by one column
+// per round -- and the two coefficient loads, requested eight steps ahead into the register just used.
+__device__ __forceinline__ void fir_mfma_f32(BankLds<float>& sh, const float* __restrict__ mf_re,
+                                             const float* __restrict__ mf_im, int wv, int lane) {
+  typedef MfmaF32 M;
+  typedef v4f Acc;
+  const int j = lane & 15, kk = lane >> 4;
+  int g = wv == 0 ? 0 : 1 + 65 * wv;
+  const int g_end = 66 + 65 * wv;
+  while (g < g_end) {
+    const FirSeg sg(g, g_end);
+    const int n = sg.n;
+    const Acc zero = {0, 0, 0, 0};
+    Acc ar0 = zero, ar1 = zero, ar2 = zero, ar3 = zero, ai0 = zero, ai1 = zero, ai2 = zero, ai3 = zero;
+    const int d = sg.d0 + 4 * sg.s0 + kk;
+    int o1[8], o2[8];                                // float offsets of x[-d - 4 k], x[-(1458 - d - 4 k)] at t = j
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int b = 16 * r + M::row(kk, i);
-      if (b < kFbBands) {
+    for (int k = 0; k < 8; ++k) {
+      o1[k] = win_off(kFbRing - d - 4 * k) + j;
+      o2[k] = win_off(d - 2 + 4 * k) + j;
+    }
+    // coefficient of K step s (clamped: the requests run up to eight steps past the end of the run)
+    auto coef = [&](const float* __restrict__ tab, int s) {
+      return tab[(size_t)min(g + s, kMfTotalSteps - 1) * 64 + lane];
+    };
+    float hr[8], hi[8];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          atomicAdd(&sh.a.re[b][16 * nt + j], (double)accr[nt][i]);
-          atomicAdd(&sh.a.im[b][16 * nt + j], (double)acci[nt][i]);
-        }
+    for (int k = 0; k < 8; ++k) {
+      hr[k] = coef(mf_re, k);
+      hi[k] = coef(mf_im, k);
+    }
+    v2f xa, xb, ya, yb;                              // the operands of the step about to run
+    auto fetch = [&](int k) {
+      const float* p1 = sh.win + o1[k];
+      const float* p2 = sh.win + o2[k];
+      xa = v2f{p1[0], p1[16]};
+      xb = v2f{p1[32], p1[48]};
+      ya = v2f{p2[0], p2[16]};
+      yb = v2f{p2[32], p2[48]};
+      o1[k] -= 1;                                    // eight steps on: 32 delays = one column
+      o2[k] += 1;
+    };
+    fetch(0);
+    auto mma8 = [&](float cr, float ci, v2f sa, v2f da, v2f sb, v2f db) {
+      ar0 = M::mma(cr, sa.x, ar0);
+      ai0 = M::mma(ci, da.x, ai0);
+      ar1 = M::mma(cr, sa.y, ar1);
+      ai1 = M::mma(ci, da.y, ai1);
+      ar2 = M::mma(cr, sb.x, ar2);
+      ai2 = M::mma(ci, db.x, ai2);
+      ar3 = M::mma(cr, sb.y, ar3);
+      ai3 = M::mma(ci, db.y, ai3);
+    };
+    int s = 0;
+    for (; s + 8 <= n; s += 8) {                     // full rounds: no branches inside
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const v2f sa = xa + ya, da = xa - ya, sb = xb + yb, db = xb - yb;
+        const float cr = hr[k], ci = hi[k];
+        fetch((k + 1) & 7);
+        hr[k] = coef(mf_re, s + k + 8);
+        hi[k] = coef(mf_im, s + k + 8);
+        __builtin_amdgcn_sched_barrier(0);           // reads and requests stay ahead of the matrix instructions
+        mma8(cr, ci, sa, da, sb, db);
       }
     }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {                    // the last n mod 8 steps (wave-uniform branches)
+      if (s + k < n) {
+        const v2f sa = xa + ya, da = xa - ya, sb = xb + yb, db = xb - yb;
+        fetch(k + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma8(hr[k], hi[k], sa, da, sb, db);
+      }
+    }
+    const Acc accr[4] = {ar0, ar1, ar2, ar3}, acci[4] = {ai0, ai1, ai2, ai3};
+    fir_store<M>(sh, sg.r, j, kk, accr, acci);
     g += n;
   }
 }
@@ -379,6 +498,20 @@ __device__ __forceinline__ void spread_up(BankLds<WT>& sh, const double (&re)[10
   }
 }
 
+// Phase timing for tools/fb_profile.py (development builds with -DPEAQ_FB_PROFILE only): cycles between
+// consecutive marks, summed per wave role over one sampled workgroup in 16.
+#ifdef PEAQ_FB_PROFILE
+__device__ unsigned long long g_fb_prof[4 * 16 + 4];
+#define FB_MARK(i)                                                                       \
+  do {                                                                                   \
+    const unsigned long long now_ = __builtin_readcyclecounter();                        \
+    if (lane == 0 && (blockIdx.x & 15) == 5) atomicAdd(&g_fb_prof[wv * 16 + (i)], now_ - prof_t_); \
+    prof_t_ = __builtin_readcyclecounter();                                              \
+  } while (0)
+#else
+#define FB_MARK(i) do { } while (0)
+#endif
+
 template <typename M>
 __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned n_signals) {
   typedef typename M::T WT;
@@ -400,6 +533,13 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
     nb_mine = n_blocks > a.block0 ? min(a.blocks_per_launch, n_blocks - a.block0) : 0;
   }
   if (nb_mine == 0) return;
+#ifdef PEAQ_FB_STAGGER
+  // the two workgroups of a CU run the same code from the same start: without an offset they sit in the
+  // FIR phase (matrix pipe) together and in the vector phases together.  The second workgroup of every CU
+  // in the first dispatch round starts half a tile late; equal run times then keep the pairs staggered.
+  if (blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < PEAQ_FB_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   const BandTables* __restrict__ bt = a.bands;
   const FbTables* __restrict__ fb = a.fb;
   const size_t row_len = a.hp_row_stride;
@@ -438,8 +578,14 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
 #pragma unroll
   for (int q = 0; q < kPre; ++q) pre[q] = 0.;
 
+#ifdef PEAQ_FB_PROFILE
+  unsigned long long prof_t_ = __builtin_readcyclecounter();
+#endif
   for (unsigned b0 = 0; b0 < nb_mine; b0 += kTileBlocks) {
     const unsigned nvb = min((unsigned)kTileBlocks, nb_mine - b0);   // valid blocks in this tile
+#ifdef PEAQ_FB_PROFILE
+    if (lane == 0 && (blockIdx.x & 15) == 5) atomicAdd(&g_fb_prof[64 + wv], 1ull);
+#endif
     const int nvs = 6 * nvb;                                         // valid sub-samples
     // (no barrier here: after the last barrier of the previous tile nobody reads the window or A
     // any more; wave 0 may still be in its phase 5, which only touches e1 and global memory)
@@ -462,12 +608,15 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       for (int i = tid; i < kFbBands * kACols; i += 256) az[i] = make_double2(0., 0.);
     }
     __syncthreads();
+    FB_MARK(0);
     // ---- phase 1: the complex FIR filters (fbearmodel.c:399-435) as a GEMM on the matrix cores ---
     if (sizeof(WT) == 8)
       fir_mfma<M>(sh, reinterpret_cast<const WT*>(fb->mf_re), reinterpret_cast<const WT*>(fb->mf_im), wv, lane);
     else
-      fir_mfma<M>(sh, reinterpret_cast<const WT*>(fb->mf_re_f), reinterpret_cast<const WT*>(fb->mf_im_f), wv, lane);
+      fir_mfma_f32(reinterpret_cast<BankLds<float>&>(sh), fb->mf_re_f, fb->mf_im_f, wv, lane);
+    FB_MARK(1);
     __syncthreads();                                                 // A is complete
+    FB_MARK(2);
     // ---- phase 2a: every wave picks up its ten bands at its time point ---------------------------
     double re[10], im[10];
 #pragma unroll
@@ -487,6 +636,7 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       sh.a.im[0][lane] = im[0];
     }
     __syncthreads();                                                 // ... before phase 2b adds into A
+    FB_MARK(3);
     // ---- the next tile's window: nobody reads this tile's any more.  Its last 45 columns become
     // the next tile's first 45 (a tile advances by 60 columns = 1920 samples); the new samples are
     // requested now and land in registers while phases 2b..5 run ---------------------------------------
@@ -504,6 +654,7 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
         pre[q] = wdx < avail ? src[wdx] : 0.;
       }
     }
+    FB_MARK(4);
     // ---- phase 2b: level-dependent upward spreading (fbearmodel.c:327-349).  The slope
     // filter runs along time = along the lanes (inclusive scan with the carried-in state);
     // every source band adds its geometric tail into the bands above it.  A wave first sums
@@ -523,13 +674,16 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       if (lane == 0) sh.cu[b] = carry;                               // only this wave touches cu[b]
       cuv[i] = cu;
     }
+    FB_MARK(5);
     switch (wv) {
       case 0: spread_up<0, WT>(sh, re, im, cuv, lane); break;
       case 1: spread_up<1, WT>(sh, re, im, cuv, lane); break;
       case 2: spread_up<2, WT>(sh, re, im, cuv, lane); break;
       default: spread_up<3, WT>(sh, re, im, cuv, lane); break;
     }
+    FB_MARK(6);
     __syncthreads();
+    FB_MARK(7);
     // ---- phase 3: downward spreading (fbearmodel.c:351-354): wave 0 the real, wave 1 the
     // imaginary parts; a column per lane ----------------------------------------------------------
     if (wv < 2) {
@@ -542,6 +696,7 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       }
     }
     __syncthreads();
+    FB_MARK(8);
     // ---- phase 4: rectification + backward masking at block rate (fbearmodel.c:357-382);
     // one (band, block) per thread --------------------------------------------------------------------
     for (int item = tid; item < kFbBands * kTileBlocks; item += 256) {
@@ -560,6 +715,7 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       sh.e1[b][blk] = e1;
     }
     __syncthreads();
+    FB_MARK(9);
     // history for the next tile: the 10 newest VALID sub-samples, oldest first
     // (400 (band, slot) items on 256 threads: two per thread)
     double hnew[2] = {0., 0.};
@@ -583,6 +739,7 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       const int item = tid + 256 * rep;
       if (item < kFbBands * 10) sh.hist[item / 10][item % 10] = hnew[rep];
     }
+    FB_MARK(10);
     // ---- phase 5: internal noise + forward masking (fbearmodel.c:385-394).  The recurrence along
     // the blocks is walked by one thread per band into LDS; then all threads write the records --------
     if (tid < kFbBands) {
@@ -595,12 +752,14 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       }
     }
     __syncthreads();
+    FB_MARK(11);
     for (int item = tid; item < kFbBands * (int)nvb; item += 256) {
       const int bl = item / kFbBands, b = item - bl * kFbBands;      // 40 consecutive doubles per block
       double* rec = a.records + ((size_t)(pair * a.blocks_per_launch + b0 + bl) * a.channels + chan) * kFbRecDoubles;
       rec[(sig ? kFbRecUnsmTest : kFbRecUnsmRef) + b] = sh.e1[b][bl];
       rec[(sig ? kFbRecExcTest : kFbRecExcRef) + b] = sh.ex[b][bl];
     }
+    FB_MARK(12);
   }
   __syncthreads();
   if (tid < kFbBands) {
@@ -634,3 +793,13 @@ hipError_t launch_fb_frontend(const FbFrontArgs& a, unsigned n_pairs, hipStream_
 }
 
 }  // namespace peaq
+
+#ifdef PEAQ_FB_PROFILE
+// development builds only: reads and clears the bank kernel's phase counters (tools/fb_profile.py)
+extern "C" int peaq_debug_fb_profile(unsigned long long* out68) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out68, HIP_SYMBOL(peaq::g_fb_prof), sizeof(peaq::g_fb_prof)) != hipSuccess) return 1;
+  static const unsigned long long zero[4 * 16 + 4] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(peaq::g_fb_prof), zero, sizeof(zero)) != hipSuccess;
+}
+#endif
