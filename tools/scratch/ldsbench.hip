@@ -18,6 +18,9 @@ __global__ __launch_bounds__(128, 3) void k(double* out, int iters) {
       if (MODE == 3) acc += __shfl(v, (lane * 5 + s) & 63, 64);                      // 2 x ds_bpermute_b32
       if (MODE == 4) { u[(lane * 17 + s * 67) & 1023] = v; }                         // ds_write_b64, scattered
       if (MODE == 5) acc += u[(lane * 17 + s * 67 + it) & 1023];                     // ds_read_b64, scattered
+      if (MODE == 6) atomicAdd(reinterpret_cast<float*>(u) + 128 * (s & 1) + lane + (s >> 1), (float)v);   // ds_add_f32
+      if (MODE == 7) atomicAdd(reinterpret_cast<float*>(u) + 128 * (s & 1) + lane + (s >> 1), (float)v * 1e-42f);   // ... denormal values
+      if (MODE == 8) acc += reinterpret_cast<float*>(u)[128 * (s & 1) + lane + (s >> 1)];            // ds_read_b32
       v += 1e-9;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -28,8 +31,8 @@ int main() {
   const int blocks = 256 * 6, iters = 2000;
   double* o; hipMalloc(&o, blocks * 128 * 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const char* names[] = {"ds_add_f64", "ds_write_b64", "ds_read_b64", "shfl(double)=2 bpermute", "ds_write_b64 scattered", "ds_read_b64 scattered"};
-  for (int mode = 0; mode < 6; ++mode) {
+  const char* names[] = {"ds_add_f64", "ds_write_b64", "ds_read_b64", "shfl(double)=2 bpermute", "ds_write_b64 scattered", "ds_read_b64 scattered", "ds_add_f32", "ds_add_f32 denormal", "ds_read_b32"};
+  for (int mode = 0; mode < 9; ++mode) {
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
       hipEventRecord(e0);
@@ -40,6 +43,9 @@ int main() {
       if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(128), lds, 0, o, iters);
       if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(128), lds, 0, o, iters);
       if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(128), lds, 0, o, iters);
+      if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(128), lds, 0, o, iters);
+      if (mode == 7) hipLaunchKernelGGL(k<7>, dim3(blocks), dim3(128), lds, 0, o, iters);
+      if (mode == 8) hipLaunchKernelGGL(k<8>, dim3(blocks), dim3(128), lds, 0, o, iters);
       hipEventRecord(e1); hipEventSynchronize(e1);
       hipEventElapsedTime(&ms, e0, e1);
     }
