@@ -196,19 +196,26 @@ __device__ __forceinline__ int spec_bin(int s, int lane) {
 }
 
 // critical-band grouping of a spectrum held in LDS (fftearmodel.c:604-620).  The interior bins are
-// fetched eight at a time (guarded: beyond the band the lane re-reads its first bin and adds zero),
-// so that a band of 25 bins costs four LDS round trips instead of 25; the order of the additions is
-// that of the plain loop.
-template <typename F>
-__device__ __forceinline__ double group_band(const BandTables* __restrict__ bt, int b, F spec) {
+// fetched eight at a time, so that a band of 25 bins costs four LDS round trips instead of 25; beyond
+// the band the lane reads sp[zero] -- a slot the caller has set to 0 -- so that the sum needs no
+// second predicate (adding +0 is exact); the order of the additions is that of the plain loop.
+__device__ __forceinline__ double group_band(const BandTables* __restrict__ bt, int b, const double* sp, int zero) {
   const int lo = bt->lo[b], hi = bt->hi[b];
-  double p = bt->wlo[b] * spec(lo) + bt->whi[b] * spec(hi);
+  double p = bt->wlo[b] * sp[lo] + bt->whi[b] * sp[hi];
   for (int k0 = lo + 1; k0 < hi; k0 += 8) {
+    typedef const __attribute__((address_space(3))) double* lds_cptr;
+    const lds_cptr q = (lds_cptr)sp + k0, z = (lds_cptr)sp + zero;
+    const int n = hi - k0;                           // bins left
     double v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = spec(k0 + j < hi ? k0 + j : lo);
+    for (int j = 0; j < 8; ++j) {
+      // one compare and one select per slot; the constant j goes into the read's offset field
+      lds_cptr qj = j < n ? q : z - j;
+      asm("" : "+v"(qj));
+      v[j] = qj[j];
+    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) p += k0 + j < hi ? v[j] : 0.;
+    for (int j = 0; j < 8; ++j) p += v[j];
   }
   return p < 1e-12 ? 1e-12 : p;
 }
@@ -489,25 +496,38 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
     }
     __syncthreads();
     thr = xch[0];
-    if (sig == 0) {
+    // One compare per slot; the rest is scalar: the compare's lane mask says which bins of the slot
+    // pass, its highest (slots 0..7: bin = 64 q + lane) or lowest (mirror slots: bin = 1024 - 64 q - lane)
+    // set bit below the limit is the slot's top bin.  Returns that bin + 1 over all slots, 0 if none.
+    auto top_bin = [&](double level, int limit, bool or_equal) {
+      int best = 0;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int k = spec_bin(s, lane);
-        if (k < 921 && pspec[s] > 10. * thr) bw_ref = max(bw_ref, k + 1);
+      for (int q = 0; q < 8; ++q) {
+        unsigned long long m = __ballot(or_equal ? pspec[q] >= level : pspec[q] > level);
+        const int nl = limit - 64 * q;               // lanes 0 .. nl - 1 hold bins below the limit
+        m &= nl >= 64 ? ~0ull : nl <= 0 ? 0ull : (1ull << nl) - 1ull;
+        if (m) best = max(best, 64 * q + 64 - __builtin_clzll(m));
       }
-      bw_ref = wave_max_i(bw_ref);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        unsigned long long m = __ballot(or_equal ? pspec[8 + q] >= level : pspec[8 + q] > level);
+        if (q == 0) {                                // lane 0 carries bin 512 here (spec_bin)
+          if ((m & 1ull) && 512 < limit) best = max(best, 513);
+          m &= ~1ull;
+        }
+        const int lo = 1024 - 64 * q - limit + 1;    // lanes lo .. 63 hold bins below the limit
+        m &= lo >= 64 ? 0ull : lo <= 0 ? ~0ull : ~0ull << lo;
+        if (m) best = max(best, 1024 - 64 * q - __builtin_ctzll(m) + 1);
+      }
+      return best;
+    };
+    if (sig == 0) {
+      bw_ref = top_bin(10. * thr, 921, false);
       if (lane == 0) xch[1] = (double)bw_ref;
     }
     __syncthreads();
     bw_ref = (int)xch[1];
-    if (sig == 1 && bw_ref > 346) {
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int k = spec_bin(s, lane);
-        if (k < bw_ref && pspec[s] >= 3.16227766016838 * thr) bw_test = max(bw_test, k + 1);
-      }
-      bw_test = wave_max_i(bw_test);
-    }
+    if (sig == 1 && bw_ref > 346) bw_test = top_bin(3.16227766016838 * thr, bw_ref, true);
   }
 
   FE_MARK(2);                                        // bandwidths (two barriers)
@@ -518,14 +538,17 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
   // All lanes of one atomic hit the same parity at consecutive idx (8-byte stride): no bank conflicts.
   double* e2up = scratch;                            // [2][128]
   for (int i = lane; i < 256; i += 64) e2up[i] = 0.;
+  constexpr int kZeroSlot = kOffScratch + 400 - kOffPw;   // a free word of the scratch area, as an index into Pw
+  if (lane == 0) scratch[400] = 0.;
+  wave_lds_fence();
   // Band sums with a balanced assignment -- lane L adds up band L (narrow) and band NB-1-L (wide):
   // the longest loop is ~27 bins instead of the ~50 of two adjacent top bands -- handed over to
   // the two-adjacent-bands layout of everything that follows through LDS.
   double* ppx = scratch + 256;                       // [NB]
   if (lane < (NB + 1) / 2) {
     const int b1 = lane, b2 = NB - 1 - lane;
-    ppx[b1] = group_band(bt, b1, [&](int k) { return pw[k]; });
-    if (b2 != b1) ppx[b2] = group_band(bt, b2, [&](int k) { return pw[k]; });
+    ppx[b1] = group_band(bt, b1, pw, kZeroSlot);
+    if (b2 != b1) ppx[b2] = group_band(bt, b2, pw, kZeroSlot);
   }
   wave_lds_fence();
   FE_MARK(3);                                        // band grouping
@@ -636,12 +659,13 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
 #pragma unroll
       for (int i = 0; i < kSteps; ++i)
         if (lane + 64 * i < kPwLen) pw_test[lane + 64 * i] = r[i] - 2 * sqrt_pos(r[i] * t[i]) + t[i];
+      if (lane == 0) lds[kOffPw] = 0.;               // the reference spectrum is dead now: its first word is the zero slot
     }
     wave_lds_fence();
     if (lane < (NB + 1) / 2) {                        // balanced assignment as above, straight to the record
       const int b1 = lane, b2 = NB - 1 - lane;
-      rec[kRecNoise + b1] = group_band(bt, b1, [&](int k) { return pw_test[k]; });
-      if (b2 != b1) rec[kRecNoise + b2] = group_band(bt, b2, [&](int k) { return pw_test[k]; });
+      rec[kRecNoise + b1] = group_band(bt, b1, pw_test, kOffPw - kUnitDoubles);
+      if (b2 != b1) rec[kRecNoise + b2] = group_band(bt, b2, pw_test, kOffPw - kUnitDoubles);
     } else if (lane < (NB + 1) / 2 + kBandStride - NB) {
       rec[kRecNoise + NB + lane - (NB + 1) / 2] = 0.;  // padding slots of the band vector
     }
