@@ -167,7 +167,7 @@ struct GlobalTabs {
   __device__ __forceinline__ double mask_diff(int b) const { return p->mask_diff[b]; }
   __device__ __forceinline__ double deriv_factor() const { return p->deriv_factor; }
 };
-enum { T_ADAPT, T_EAR, T_THR, T_LOUDF, T_EXCTHR, T_INOISE, T_NPOW03, T_MASK, T_COUNT };
+enum { T_ADAPT, T_EAR, T_THR, T_LOUDF, T_EXCTHR, T_INOISE, T_NPOW03, T_MASK, T_ISN, T_ISN03, T_COUNT };
 struct LdsTabs {
   const double* t;                  // [T_COUNT][kBandStride] in LDS
   int off;                          // 0, but opaque to the compiler (re-read per frame, not hoisted)
@@ -376,7 +376,8 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
   {
     const BandTables* __restrict__ g = a.bands;
     const double* const src[T_COUNT] = {g->adapt_tc, g->ear_tc, g->threshold, g->loud_factor, g->exc_threshold,
-                                        g->internal_noise, g->noise_pow03, g->mask_diff};
+                                        g->internal_noise, g->noise_pow03, g->mask_diff, g->inv_spread_norm,
+                                        g->inv_spread_norm_pow03};
 #pragma unroll
     for (int t = 0; t < T_COUNT; ++t)
       for (int i = threadIdx.x; i < kBandStride; i += blockDim.x) sh_tab[t * kBandStride + i] = src[t][i];
@@ -449,13 +450,16 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
     {
       const int b0 = bl.band(0);
       const int bb = b0 < kBandStride ? b0 : 0;
-      const double2 v0 = *reinterpret_cast<const double2*>(rec + kRecUnsmRef + bb);
-      const double2 v1 = *reinterpret_cast<const double2*>(rec + kRecUnsmTest + bb);
-      const double2 v2 = *reinterpret_cast<const double2*>(rec + kRecLoudRef + bb);
-      const double2 v3 = *reinterpret_cast<const double2*>(rec + kRecLoudTest + bb);
+      const double2 v0 = *reinterpret_cast<const double2*>(rec + kRecRootRef + bb);
+      const double2 v1 = *reinterpret_cast<const double2*>(rec + kRecRootTest + bb);
       const double2 v4 = *reinterpret_cast<const double2*>(rec + kRecNoise + bb);
-      ur[0] = v0.x; ur[1] = v0.y; ut[0] = v1.x; ut[1] = v1.y;
-      lr[0] = v2.x; lr[1] = v2.y; lt[0] = v3.x; lt[1] = v3.y;
+      // unsmeared excitation (fftearmodel.c:593-597) and its 0.3rd power (modpatt.c:235) from the roots
+      const double n0 = bt.at(T_ISN, bb), n1 = bt.at(T_ISN, bb + 1);
+      const double m0 = bt.at(T_ISN03, bb), m1 = bt.at(T_ISN03, bb + 1);
+      excitation_from_root(v0.x, n0, m0, ur[0], lr[0]);
+      excitation_from_root(v0.y, n1, m1, ur[1], lr[1]);
+      excitation_from_root(v1.x, n0, m0, ut[0], lt[0]);
+      excitation_from_root(v1.y, n1, m1, ut[1], lt[1]);
       nz[0] = v4.x; nz[1] = v4.y;
     }
     // time smearing, fftearmodel.c:496-504

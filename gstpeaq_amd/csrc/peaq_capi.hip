@@ -31,7 +31,7 @@
 using namespace peaq;
 
 static_assert(sizeof(ResultRecord) == sizeof(peaq_result), "result layouts must match");
-static_assert(kRecDoubles == PEAQ_DEBUG_RECORD_DOUBLES, "record layouts must match");
+static_assert(kPubDoubles == PEAQ_DEBUG_RECORD_DOUBLES, "record layouts must match");
 static_assert(kDbgDoubles == PEAQ_DEBUG_BACKEND_DOUBLES, "debug layouts must match");
 
 // ---------------------------------------------------------------------------
@@ -640,10 +640,26 @@ extern "C" int peaq_debug_frontend(peaq_ctx* c, int bands, int channels, double 
   fa.common = c->d_common;
   fa.bands = bands == 109 ? c->d_bands109 : c->d_bands55;
   fa.records = d_rec;
+  std::vector<double> h_rec((size_t)n_frames * channels * kRecDoubles);
   hipError_t e = launch_frontend(bands, fa, 1, nullptr);
   if (e == hipSuccess) e = hipDeviceSynchronize();
-  if (e == hipSuccess) e = hipMemcpy(host_out, d_rec, bytes, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(h_rec.data(), d_rec, bytes, hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail(PEAQ_ERR_DEVICE, std::string("peaq_debug_frontend: ") + hipGetErrorString(e));
+  // the test-facing layout spells the two derived vectors out (the back end's own arithmetic, on the host)
+  BandTables t;
+  build_fft_band_tables(bands, t);
+  for (size_t r = 0; r < (size_t)n_frames * channels; ++r) {
+    const double* in = h_rec.data() + r * kRecDoubles;
+    double* out = host_out + r * kPubDoubles;
+    for (int b = 0; b < kBandStride; ++b) {
+      excitation_from_root(in[kRecRootRef + b], t.inv_spread_norm[b], t.inv_spread_norm_pow03[b], out[kPubUnsmRef + b],
+                           out[kPubLoudRef + b]);
+      excitation_from_root(in[kRecRootTest + b], t.inv_spread_norm[b], t.inv_spread_norm_pow03[b],
+                           out[kPubUnsmTest + b], out[kPubLoudTest + b]);
+      out[kPubNoise + b] = in[kRecNoise + b];
+    }
+    for (int i = 0; i < kPubDoubles - kPubScalars; ++i) out[kPubScalars + i] = in[kRecScalars + i];
+  }
   return PEAQ_OK;
 }
 
@@ -713,7 +729,24 @@ extern "C" int peaq_debug_backend(peaq_ctx* c, int channels, int n_frames, const
   HIP_TRY(dbg.reserve(dbg_bytes));
   HIP_TRY(st.reserve(sizeof(PairState)));
   HIP_TRY(res.reserve(sizeof(ResultRecord)));
-  HIP_TRY(hipMemcpy(recs.p, host_records, rec_bytes, hipMemcpyHostToDevice));
+  {
+    // test-facing layout -> the record the kernels exchange: root = (E norm)^(1/10); the E^0.3 vector of the
+    // input is implied by E (the back end derives both from the root)
+    BandTables t;
+    build_fft_band_tables(109, t);
+    std::vector<double> h_rec((size_t)n_frames * channels * kRecDoubles, 0.);
+    for (size_t r = 0; r < (size_t)n_frames * channels; ++r) {
+      const double* in = host_records + r * kPubDoubles;
+      double* out = h_rec.data() + r * kRecDoubles;
+      for (int b = 0; b < 109; ++b) {
+        out[kRecRootRef + b] = std::pow(in[kPubUnsmRef + b] / t.inv_spread_norm[b], 0.1);
+        out[kRecRootTest + b] = std::pow(in[kPubUnsmTest + b] / t.inv_spread_norm[b], 0.1);
+      }
+      for (int b = 0; b < kBandStride; ++b) out[kRecNoise + b] = in[kPubNoise + b];
+      for (int i = 0; i < kRecDoubles - kRecScalars; ++i) out[kRecScalars + i] = in[kPubScalars + i];
+    }
+    HIP_TRY(hipMemcpy(recs.p, h_rec.data(), rec_bytes, hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMemset(dbg.p, 0, dbg_bytes));
   HIP_TRY(launch_state_init(st.as<PairState>(), 0, 1, nullptr));
   BackendArgs ba{};

@@ -91,13 +91,14 @@ struct FbTables {               // fbearmodel.c:57-61,182-225
 };
 
 // ---- per-frame record: front end -> back end --------------------------------
-// One record per (pair, frame, channel), kRecDoubles doubles.
-constexpr int kRecUnsmRef   = 0 * kBandStride;   // unsmeared excitation, reference
-constexpr int kRecUnsmTest  = 1 * kBandStride;
-constexpr int kRecLoudRef   = 2 * kBandStride;   // unsmeared^0.3 (modpatt.c:235)
-constexpr int kRecLoudTest  = 3 * kBandStride;
-constexpr int kRecNoise     = 4 * kBandStride;   // noise in bands (movs.c:992-1000)
-constexpr int kRecScalars   = 5 * kBandStride;   // 560
+// One record per (pair, frame, channel), kRecDoubles doubles: what the stateless front end hands to the
+// back end.  The excitation travels as ONE number per band and signal, root = E2^(1/4) of the spread band
+// energy E2 (fftearmodel.c:556-597): the unsmeared excitation E = E2^2.5 / norm and E^0.3 (modpatt.c:235)
+// are both a few multiplications away (excitation_from_root), so neither needs its own vector.
+constexpr int kRecRootRef   = 0 * kBandStride;
+constexpr int kRecRootTest  = 1 * kBandStride;
+constexpr int kRecNoise     = 2 * kBandStride;   // noise in bands (movs.c:992-1000)
+constexpr int kRecScalars   = 3 * kBandStride;   // 336
 constexpr int kRecBwRef     = kRecScalars + 0;
 constexpr int kRecBwTest    = kRecScalars + 1;
 constexpr int kRecEhs       = kRecScalars + 2;   // EHS of this frame (not yet x1000)
@@ -105,7 +106,27 @@ constexpr int kRecFlagsRef  = kRecScalars + 3;   // bit0 above-threshold (ref), 
 constexpr int kRecFlagsTest = kRecScalars + 4;   // bit1 energy(test)
 constexpr int kRecSigE      = kRecScalars + 5;   // sum ref^2 over the hop (totalsnr)
 constexpr int kRecNoiseE    = kRecScalars + 6;   // sum (ref-test)^2
-constexpr int kRecDoubles   = 576;               // == PEAQ_DEBUG_RECORD_DOUBLES
+constexpr int kRecDoubles   = 352;
+
+// E = E2^2.5 / norm = root^10 inv_norm (fftearmodel.c:593-597) and E^0.3 = root^3 inv_norm^0.3
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline void excitation_from_root(double root, double inv_norm, double inv_norm_pow03, double& unsm, double& loud) {
+  const double r1 = root * root, e2 = r1 * r1;
+  unsm = e2 * e2 * r1 * inv_norm;
+  loud = r1 * root * inv_norm_pow03;
+}
+
+// The layout peaq_debug_frontend / peaq_debug_backend show to the parity tests (include/peaq_amd.h,
+// PEAQ_DEBUG_RECORD_DOUBLES): the record with both derived vectors written out.
+constexpr int kPubUnsmRef   = 0 * kBandStride;   // unsmeared excitation, reference
+constexpr int kPubUnsmTest  = 1 * kBandStride;
+constexpr int kPubLoudRef   = 2 * kBandStride;   // unsmeared^0.3 (modpatt.c:235)
+constexpr int kPubLoudTest  = 3 * kBandStride;
+constexpr int kPubNoise     = 4 * kBandStride;
+constexpr int kPubScalars   = 5 * kBandStride;   // 560: the scalars in the order of kRecScalars
+constexpr int kPubDoubles   = 576;               // == PEAQ_DEBUG_RECORD_DOUBLES
 
 // stage-level dump of the back end (peaq_debug_backend): per (frame, channel) the patterns the
 // reference's pattern layer hands to the MOV layer

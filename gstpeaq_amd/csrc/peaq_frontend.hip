@@ -601,22 +601,16 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
     dn1 = ene[1] + al * nxt;
   }
   wave_lds_fence();
-  double unsm[2], loud[2];
+  // (25): the excitation is E2^(1/0.4) / normalisation; the record carries E2^(1/4), from which the back
+  // end gets E and E^0.3 by multiplications (excitation_from_root, peaq_device.h)
+  double root[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int b = b0 + s;
     const double e2 = (s ? dn1 : dn0) + e2up[128 * s + lane];   // band 2 lane + s
-    // (25): E = E2^(1/0.4) / normalisation, and E^0.3 for the modulation patterns (modpatt.c:235),
-    // both from square roots: x^2.5 = x^2 sqrt(x), (x^2.5)^0.3 = x^0.75 = sqrt(x) sqrt(sqrt(x))
-    const int bb = b < NB ? b : 0;
-    const double r1 = sqrt_pos(e2), r2 = sqrt_pos(r1);
-    unsm[s] = b < NB ? e2 * e2 * r1 * bt->inv_spread_norm[bb] : 0.;
-    loud[s] = b < NB ? r1 * r2 * bt->inv_spread_norm_pow03[bb] : 0.;
+    root[s] = b0 + s < NB ? sqrt_pos(sqrt_pos(e2)) : 0.;
   }
-  if (b0 < kBandStride) {
-    *reinterpret_cast<double2*>(rec + (sig ? kRecUnsmTest : kRecUnsmRef) + b0) = make_double2(unsm[0], unsm[1]);
-    *reinterpret_cast<double2*>(rec + (sig ? kRecLoudTest : kRecLoudRef) + b0) = make_double2(loud[0], loud[1]);
-  }
+  if (b0 < kBandStride)
+    *reinterpret_cast<double2*>(rec + (sig ? kRecRootTest : kRecRootRef) + b0) = make_double2(root[0], root[1]);
 
   FE_MARK(6);                                        // downward spreading, excitation, record
   __syncthreads();                                   // both spectra are in LDS

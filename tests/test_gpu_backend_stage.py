@@ -63,8 +63,10 @@ def test_level_adapter_against_testpeaq_vectors(gpu, tp):
     ref = np.arange(1, NB + 1, dtype=np.float64)
     test = np.arange(NB, 0, -1, dtype=np.float64)
     d, _ = capi.debug_backend(gpu.ctx(), hand_records(2, ref, test))
-    np.testing.assert_array_equal(d["exc_ref"][0, 0], ref)
-    np.testing.assert_array_equal(d["exc_test"][1, 0], test)
+    # (the kernels exchange E2^(1/4) per band, peaq_device.h: the hand-built E goes through a tenth root and
+    # back, so it arrives with a few ulp of rounding, not bit for bit)
+    np.testing.assert_allclose(d["exc_ref"][0, 0], ref, rtol=1e-13)
+    np.testing.assert_allclose(d["exc_test"][1, 0], test, rtol=1e-13)
     tol = tp["_tolerance"]
     assert_testpeaq_close(d["adapted_ref"][0, 0], tp["spectrally_adapted_ref_patterns1_ref"], tol)
     assert_testpeaq_close(d["adapted_test"][0, 0], tp["spectrally_adapted_test_patterns1_ref"], tol)
