@@ -221,7 +221,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # PEAQ_BENCH_FORCE_DIST=1: build the communicator also for one rank, so that a one-GPU box can run the
+    # RCCL calls of the N > 1 path (tests/test_gpu_rccl_single.py)
+    if world > 1 or os.environ.get("PEAQ_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
@@ -369,7 +371,9 @@ def main():
             "config": {"workload": workload, "pairs_per_gpu": pairs_per_gpu, "total_pairs": total_pairs,
                        "frame_pairs_per_pair": m["fp_rank"] / (hi - lo),
                        "waves_per_step": (hi - lo + wave_pairs - 1) // wave_pairs if waves_mode else 1,
-                       "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
+                       "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
+                       "result_gather": f"{dist.get_backend()} all_gather over {dist.get_world_size()} rank(s)" if dist
+                       else "none (one process)"},
             "roofline": filterbank_roofline(m) if main_adv else frontend_roofline(m, False),
             "odg_mean": float(odg[~torch.isnan(odg)].mean().item()),
             "odg_nan": int(torch.isnan(odg).sum().item()),

@@ -45,7 +45,7 @@ def gather_results(local, world, dist=None):
     """local: tensor [n_local, k] of result records -> [n_total, k] on every rank,
     in pair order.  Shards may differ in size by one."""
     import torch
-    if world == 1 or dist is None:
+    if dist is None:                      # single process, no communicator
         return local
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
