@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -1171,6 +1173,89 @@ struct BrokerStage {
     }
   }
 };
+
+// what one session contributes to a tick: decided under the slot lock in the tick's serial scan,
+// copied into the staging buffers afterwards (by the staging threads, several sessions at a time)
+struct BrokerJob {
+  int sid = 0;
+  bool fft = false, fb = false;
+  unsigned fft_idx = 0, fb_idx = 0;
+  uint64_t fft_from[2] = {0, 0}, fft_n[2] = {0, 0};
+  uint64_t fb_from[2] = {0, 0}, fb_n[2] = {0, 0};
+};
+
+// A few helper threads for the tick's one heavy host-side step, the copy of every session's new samples
+// into the pinned staging buffers (147 KB per stereo session and tick: with 1024 sessions one thread
+// spends 12 ms per tick on it).  run(n, fn) calls fn(i) for i in [0, n) on the helpers and the caller.
+class StagePool {
+ public:
+  explicit StagePool(unsigned helpers) {
+    for (unsigned i = 0; i < helpers; ++i) threads_.emplace_back([this] { loop(); });
+  }
+  ~StagePool() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      stop_ = true;
+    }
+    cv_start_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  template <typename F>
+  void run(size_t n, F&& fn) {
+    if (threads_.empty() || n < 32) {
+      for (size_t i = 0; i < n; ++i) fn(i);
+      return;
+    }
+    std::function<void(size_t)> f = fn;
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      fn_ = &f;
+      n_ = n;
+      next_.store(0);
+      busy_ = (unsigned)threads_.size();
+      ++epoch_;
+    }
+    cv_start_.notify_all();
+    work();
+    std::unique_lock<std::mutex> l(mu_);
+    cv_done_.wait(l, [this] { return busy_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      const size_t i0 = next_.fetch_add(8);
+      if (i0 >= n_) return;
+      for (size_t i = i0; i < std::min(n_, i0 + 8); ++i) (*fn_)(i);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_start_.wait(l, [&] { return stop_ || epoch_ != seen; });
+        if (stop_) return;
+        seen = epoch_;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> l(mu_);
+        if (--busy_ == 0) cv_done_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_start_, cv_done_;
+  const std::function<void(size_t)>* fn_ = nullptr;
+  size_t n_ = 0;
+  std::atomic<size_t> next_{0};
+  unsigned busy_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+};
 }  // namespace
 
 struct peaq_broker {
@@ -1197,6 +1282,8 @@ struct peaq_broker {
   std::condition_variable tick_cv;
   uint64_t n_ticks = 0, n_launches = 0, n_frames = 0;
   uint32_t max_active = 0;
+  std::vector<BrokerJob> jobs;      // this tick's staging work
+  std::unique_ptr<StagePool> stagers;
 };
 
 // copies nv[p] samples per pad from the slot's FIFOs at pos[] into staging entry `idx`
@@ -1228,10 +1315,13 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
   uint32_t* m_fb_ntest = b->h_meta + 6 * S;
   unsigned active = 0, max_nf = 0, fb_active = 0, max_nb = 0;
   uint64_t frames = 0;
+  b->jobs.clear();
   for (int sid = 0; sid < b->max_sessions; ++sid) {
     BrokerSlot& sl = *b->slots[sid];
     std::lock_guard<std::mutex> lock(sl.mu);
     if (!sl.open) continue;
+    BrokerJob job;
+    job.sid = sid;
     // ---- FFT frames: do_processing, else the one zero-padded frame of do_flush -------------------
     {
       const uint64_t left[2] = {sl.pad[0].total - sl.fft_pos[0], sl.pad[1].total - sl.fft_pos[1]};
@@ -1251,7 +1341,12 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
         }
       }
       if (nf) {
-        broker_stage_copy(b, sl, b->fft, active, sl.fft_pos, nv);
+        job.fft = true;
+        job.fft_idx = active;
+        for (int p = 0; p < 2; ++p) {
+          job.fft_from[p] = sl.fft_pos[p];
+          job.fft_n[p] = nv[p];
+        }
         m_nref[active] = static_cast<uint32_t>(nv[0]);
         m_ntest[active] = static_cast<uint32_t>(nv[1]);
         m_f0[active] = sl.frames_done;
@@ -1283,7 +1378,12 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
         }
       }
       if (nb) {
-        broker_stage_copy(b, sl, b->fbs, fb_active, sl.fb_pos, nv);
+        job.fb = true;
+        job.fb_idx = fb_active;
+        for (int p = 0; p < 2; ++p) {
+          job.fb_from[p] = sl.fb_pos[p];
+          job.fb_n[p] = nv[p];
+        }
         m_fb_nref[fb_active] = static_cast<uint32_t>(nv[0]);
         m_fb_ntest[fb_active] = static_cast<uint32_t>(nv[1]);
         b->h_win[fb_active] = FbPairWindow{sl.blocks_done, nb, sl.fb_prev_blocks, static_cast<uint32_t>(sid)};
@@ -1297,15 +1397,24 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
     }
     if (sl.flush_requested && sl.fft_flushed && (!b->advanced || sl.fb_flushed))
       sl.flush_requested = sl.fft_flushed = sl.fb_flushed = false;
-    // drop what both consumers are done with
-    for (int p = 0; p < 2; ++p) {
-      PadFifo& f = sl.pad[p];
-      const uint64_t keep_from = b->advanced ? std::min(sl.fft_pos[p], sl.fb_pos[p]) : sl.fft_pos[p];
-      f.drop_until(keep_from, b->channels);
-    }
+    if (job.fft || job.fb) b->jobs.push_back(job);
   }
   ++b->n_ticks;
   if (!active && !fb_active) return PEAQ_OK;
+  // ---- the sessions' new samples into the pinned staging buffers; then drop what both consumers are done
+  // with.  (Only ticks consume, and ticks are serialised: the positions recorded above stay valid; a
+  // concurrent push may reallocate a FIFO, hence the slot lock around each copy.) ----------------------
+  b->stagers->run(b->jobs.size(), [b](size_t i) {
+    const BrokerJob& j = b->jobs[i];
+    BrokerSlot& sl = *b->slots[j.sid];
+    std::lock_guard<std::mutex> lock(sl.mu);
+    if (j.fft) broker_stage_copy(b, sl, b->fft, j.fft_idx, j.fft_from, j.fft_n);
+    if (j.fb) broker_stage_copy(b, sl, b->fbs, j.fb_idx, j.fb_from, j.fb_n);
+    for (int p = 0; p < 2; ++p) {
+      const uint64_t keep_from = b->advanced ? std::min(sl.fft_pos[p], sl.fb_pos[p]) : sl.fft_pos[p];
+      sl.pad[p].drop_until(keep_from, b->channels);
+    }
+  });
   HIP_TRY(hipMemcpyAsync(b->d_meta.p, b->h_meta, 7 * S * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
   const uint32_t* d_meta = b->d_meta.as<uint32_t>();
   if (active) {
@@ -1418,6 +1527,14 @@ extern "C" int peaq_broker_create(peaq_ctx* c, int advanced, int channels, doubl
   b->channels = channels;
   b->level_db = level_db;
   b->max_sessions = max_sessions;
+  {
+    // staging helpers beside the ticking thread: PEAQ_AMD_BROKER_STAGERS (default 3, 0 = none); idle
+    // unless a tick has at least 32 sessions' samples to copy
+    const char* e = std::getenv("PEAQ_AMD_BROKER_STAGERS");
+    const long want = e && *e ? std::strtol(e, nullptr, 10) : 3;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    b->stagers.reset(new StagePool(max_sessions >= 32 ? (unsigned)std::min<long>(std::max<long>(want, 0), hw - 1) : 0));
+  }
   b->slots.reserve(max_sessions);
   for (int i = 0; i < max_sessions; ++i) b->slots.push_back(new BrokerSlot);
   const size_t S = (size_t)max_sessions;
