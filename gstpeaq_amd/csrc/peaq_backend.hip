@@ -730,21 +730,38 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
   const bool owns = lane == MA_RMSMOD || lane == MA_NLASYM || lane == MA_LINDIST;
   unsigned loud_reached = ps->loudness_reached;
 
-  for (unsigned blk = b_begin; blk < b_end; ++blk) {
+  // the block's values are requested one block ahead: the walk is a chain of dependent transcendental
+  // arithmetic, a record load per block would add its full memory latency 320 times per launch
+  const int lb = lane < NB ? lane : 0;
+  struct BlockIn {
+    double ur, ut, er, et, f0, f1;
+  };
+  auto fetch = [&](unsigned blk) {
     const double* __restrict__ rec0 =
         a.records + ((size_t)(pair * a.blocks_per_launch + (blk - b_begin)) * channels) * kFbRecDoubles;
     const double* __restrict__ rec = rec0 + (size_t)chan * kFbRecDoubles;
+    BlockIn in;
+    in.ur = rec[kFbRecUnsmRef + lb];
+    in.ut = rec[kFbRecUnsmTest + lb];
+    in.er = rec[kFbRecExcRef + lb];
+    in.et = rec[kFbRecExcTest + lb];
+    in.f0 = rec0[kFbRecFlags];
+    in.f1 = channels == 2 ? rec0[kFbRecDoubles + kFbRecFlags] : 0.;
+    return in;
+  };
+  BlockIn nxt = fetch(b_begin);
+  for (unsigned blk = b_begin; blk < b_end; ++blk) {
+    const BlockIn cur = nxt;
+    if (blk + 1 < b_end) nxt = fetch(blk + 1);
     // boundary detector on the 192-sample block, any reference channel (gstpeaq.c:971-979)
-    bool above = rec0[kFbRecFlags] != 0.;
-    if (channels == 2) above = above || rec0[kFbRecDoubles + kFbRecFlags] != 0.;
+    const bool above = cur.f0 != 0. || cur.f1 != 0.;
     if (owns) acc.set_tentative(!above);
 
     double ur[SLOTS], ut[SLOTS], er[SLOTS], et[SLOTS], lr[SLOTS], lt[SLOTS];
-    const int lb = lane < NB ? lane : 0;
-    ur[0] = rec[kFbRecUnsmRef + lb];
-    ut[0] = rec[kFbRecUnsmTest + lb];
-    er[0] = rec[kFbRecExcRef + lb];
-    et[0] = rec[kFbRecExcTest + lb];
+    ur[0] = cur.ur;
+    ut[0] = cur.ut;
+    er[0] = cur.er;
+    et[0] = cur.et;
     lr[0] = pow_pos(ur[0], 0.3);                     // modpatt.c:235
     lt[0] = pow_pos(ut[0], 0.3);
     double ad_ref[SLOTS], ad_test[SLOTS], mr[SLOTS], mt[SLOTS];

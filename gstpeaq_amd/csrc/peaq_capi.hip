@@ -260,10 +260,20 @@ extern "C" int peaq_debug_frontend_profile(peaq_ctx* c, unsigned long long* out6
 // batch
 // ---------------------------------------------------------------------------
 static const size_t kRecordBudget = (size_t)1536 << 20;   // HBM for per-frame records of one chunk
-static const unsigned kFbBlocksPerChunk = 320;             // filter-bank blocks per launch (multiple of 10)
-static const size_t kFbRowBudget = (size_t)12 << 30;       // HBM for ONE buffer of high-passed rows
+// Filter-bank blocks per launch (a multiple of the tile of 10) and the HBM one buffer of high-passed rows
+// may take.  Long launches pay: per block the bank kernel costs 0.150 ms in launches of 320 blocks, 0.142 at
+// 840 (fewer drained-CU tails, fewer pipeline hand-overs) -- 4096 stereo pairs x 10 s: 4.57 -> 4.74 M
+// frame-pairs/s for 2 x 21 GB of rows + 18 GB of block records, small change on a 288 GB device.
+#ifndef PEAQ_FB_CHUNK
+#define PEAQ_FB_CHUNK 840
+#endif
+#ifndef PEAQ_FB_ROWGB
+#define PEAQ_FB_ROWGB 24
+#endif
+static const unsigned kFbBlocksPerChunk = PEAQ_FB_CHUNK;
+static const size_t kFbRowBudget = (size_t)PEAQ_FB_ROWGB << 30;
 
-// blocks per launch of the filter-bank path: 320 (32 tiles) unless the batch is so large that the
+// blocks per launch of the filter-bank path: kFbBlocksPerChunk unless the batch is so large that the
 // rows of that many blocks would not fit the budget; always a multiple of the tile (10 blocks)
 static unsigned fb_blocks_per_chunk(int n_pairs, int channels, uint32_t max_blocks) {
   const size_t n_signals = (size_t)n_pairs * channels * 2;
