@@ -480,8 +480,10 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
   FE_MARK(1);                                        // FFT + split
   // ---- bandwidths (movs.c:776-809) on the unweighted spectra, straight from the registers.
   // Both waves are in lock step here, the two barriers are cheap.
+  // The advanced version has no bandwidth MOVs (gstpeaq.c:924-959): its 55-band kernel skips them.
+  constexpr bool kAdvanced = NB == 55;
   int bw_ref = 0, bw_test = 0;
-  {
+  if (!kAdvanced) {
     // [2] exchanged scalars, at the end of the reference unit's scratch: that is beyond what the
     // spreading phase uses and gets overwritten only after the next barrier but one
     double* xch = lds + kOffScratch + 510;
@@ -532,86 +534,90 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
 
   FE_MARK(2);                                        // bandwidths (two barriers)
   // ---- critical bands, internal noise, spreading ------------------------------------
-  // lane owns bands 2*lane and 2*lane+1
-  const double* pw = unit + kOffPw;
-  // upward-spreading accumulators, split by target parity: up[par][idx] = E2up[2 idx + par].
-  // All lanes of one atomic hit the same parity at consecutive idx (8-byte stride): no bank conflicts.
-  double* e2up = scratch;                            // [2][128]
-  for (int i = lane; i < 256; i += 64) e2up[i] = 0.;
-  constexpr int kZeroSlot = kOffScratch + 400 - kOffPw;   // a free word of the scratch area, as an index into Pw
-  if (lane == 0) scratch[400] = 0.;
-  wave_lds_fence();
-  // Band sums with a balanced assignment -- lane L adds up band L (narrow) and band NB-1-L (wide):
-  // the longest loop is ~27 bins instead of the ~50 of two adjacent top bands -- handed over to
-  // the two-adjacent-bands layout of everything that follows through LDS.
-  double* ppx = scratch + 256;                       // [NB]
-  if (lane < (NB + 1) / 2) {
-    const int b1 = lane, b2 = NB - 1 - lane;
-    ppx[b1] = group_band(bt, b1, pw, kZeroSlot);
-    if (b2 != b1) ppx[b2] = group_band(bt, b2, pw, kZeroSlot);
-  }
-  wave_lds_fence();
-  FE_MARK(3);                                        // band grouping
-  double ene[2], ae[2];
-  const int b0 = 2 * lane;
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int b = b0 + s;
-    if (b < NB) {
-      const double pp = ppx[b] + bt->internal_noise[b];                                            // :483-485
-      // Kabal (23)-(24); fftearmodel.c:649-656.  a^y evaluated as exp(y ln a); the three powers of
-      // aUCE share one exponential (t = aUCE^0.2: aUCE^0.4 = t^2, aUCE = t^5), and En^0.4 takes its
-      // logarithm as ln Pp - ln(gIL + gIU - 1) instead of dividing first
-      const double ln_pp = log_pos(pp);
-      const double ln_a = bt->ln_aUC[b] + bt->dz02 * ln_pp;
-      const double t = exp_fast(0.2 * ln_a), t2 = t * t;
-      const double a_uce = t2 * t2 * t;
-      const double g_iu = div_fast(1. - exp_fast((double)(NB - b) * ln_a), 1. - a_uce);
-      ae[s] = t2;
-      ene[s] = exp_fast(0.4 * (ln_pp - log_pos(bt->gIL[b] + g_iu - 1.)));
-    } else {
-      ae[s] = 0.;
-      ene[s] = 0.;
+  // (advanced version: of the test signal only the weighted spectrum is used -- noise in bands and EHS,
+  // process_fft_block_advanced gstpeaq.c:924-959 -- so its wave goes straight to the barrier)
+  if (!kAdvanced || sig == 0) {
+    // lane owns bands 2*lane and 2*lane+1
+    const double* pw = unit + kOffPw;
+    // upward-spreading accumulators, split by target parity: up[par][idx] = E2up[2 idx + par].
+    // All lanes of one atomic hit the same parity at consecutive idx (8-byte stride): no bank conflicts.
+    double* e2up = scratch;                            // [2][128]
+    for (int i = lane; i < 256; i += 64) e2up[i] = 0.;
+    constexpr int kZeroSlot = kOffScratch + 400 - kOffPw;   // a free word of the scratch area, as an index into Pw
+    if (lane == 0) scratch[400] = 0.;
+    wave_lds_fence();
+    // Band sums with a balanced assignment -- lane L adds up band L (narrow) and band NB-1-L (wide):
+    // the longest loop is ~27 bins instead of the ~50 of two adjacent top bands -- handed over to
+    // the two-adjacent-bands layout of everything that follows through LDS.
+    double* ppx = scratch + 256;                       // [NB]
+    if (lane < (NB + 1) / 2) {
+      const int b1 = lane, b2 = NB - 1 - lane;
+      ppx[b1] = group_band(bt, b1, pw, kZeroSlot);
+      if (b2 != b1) ppx[b2] = group_band(bt, b2, pw, kZeroSlot);
     }
-  }
-  wave_lds_fence();
-  FE_MARK(4);                                        // logarithms / exponentials per band
-  // upward spreading, Kabal (27): E2[j] += Ene[i] * aUCEe[i]^(j-i) for j > i.
-  // The lane's two bands 2 lane and 2 lane + 1 reach target 2 lane + s after s and s - 1 steps:
-  // their contributions are added in registers and leave as ONE LDS atomic per step; the
-  // targets of one instruction are distinct (consecutive slots of one parity), no contention.
-  {
-    double r0 = ene[0] * ae[0], r1 = ene[1];         // r0 = Ene[2 lane] a^s, r1 = Ene[2 lane + 1] a^(s-1)
-    atomicAdd(&e2up[128 + lane], r0);                // s = 1: target 2 lane + 1, band 2 lane alone
+    wave_lds_fence();
+    FE_MARK(3);                                        // band grouping
+    double ene[2], ae[2];
+    const int b0 = 2 * lane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int b = b0 + s;
+      if (b < NB) {
+        const double pp = ppx[b] + bt->internal_noise[b];                                            // :483-485
+        // Kabal (23)-(24); fftearmodel.c:649-656.  a^y evaluated as exp(y ln a); the three powers of
+        // aUCE share one exponential (t = aUCE^0.2: aUCE^0.4 = t^2, aUCE = t^5), and En^0.4 takes its
+        // logarithm as ln Pp - ln(gIL + gIU - 1) instead of dividing first
+        const double ln_pp = log_pos(pp);
+        const double ln_a = bt->ln_aUC[b] + bt->dz02 * ln_pp;
+        const double t = exp_fast(0.2 * ln_a), t2 = t * t;
+        const double a_uce = t2 * t2 * t;
+        const double g_iu = div_fast(1. - exp_fast((double)(NB - b) * ln_a), 1. - a_uce);
+        ae[s] = t2;
+        ene[s] = exp_fast(0.4 * (ln_pp - log_pos(bt->gIL[b] + g_iu - 1.)));
+      } else {
+        ae[s] = 0.;
+        ene[s] = 0.;
+      }
+    }
+    wave_lds_fence();
+    FE_MARK(4);                                        // logarithms / exponentials per band
+    // upward spreading, Kabal (27): E2[j] += Ene[i] * aUCEe[i]^(j-i) for j > i.
+    // The lane's two bands 2 lane and 2 lane + 1 reach target 2 lane + s after s and s - 1 steps:
+    // their contributions are added in registers and leave as ONE LDS atomic per step; the
+    // targets of one instruction are distinct (consecutive slots of one parity), no contention.
+    {
+      double r0 = ene[0] * ae[0], r1 = ene[1];         // r0 = Ene[2 lane] a^s, r1 = Ene[2 lane + 1] a^(s-1)
+      atomicAdd(&e2up[128 + lane], r0);                // s = 1: target 2 lane + 1, band 2 lane alone
 #pragma unroll 12
-    for (int s = 2; s <= NB; ++s) {
-      r0 *= ae[0];
-      r1 *= ae[1];
-      atomicAdd(&e2up[128 * (s & 1) + lane + (s >> 1)], r0 + r1);
+      for (int s = 2; s <= NB; ++s) {
+        r0 *= ae[0];
+        r1 *= ae[1];
+        atomicAdd(&e2up[128 * (s & 1) + lane + (s >> 1)], r0 + r1);
+      }
     }
-  }
-  FE_MARK(5);                                        // upward spreading loop
-  // downward spreading, Kabal (28): E2[i-1] = aLe E2[i] + Ene[i-1]  (suffix scan)
-  double dn0, dn1;
-  {
-    const double al = bt->aLe;
-    const double v = wave_suffix_geometric(ene[0] + al * ene[1], al * al, lane);   // pair-local, then over the lanes
-    const double nxt = lane_above(v);                // E2down[2 lane + 2]; 0 beyond the last lane
-    dn0 = v;
-    dn1 = ene[1] + al * nxt;
-  }
-  wave_lds_fence();
-  // (25): the excitation is E2^(1/0.4) / normalisation; the record carries E2^(1/4), from which the back
-  // end gets E and E^0.3 by multiplications (excitation_from_root, peaq_device.h)
-  double root[2];
+    FE_MARK(5);                                        // upward spreading loop
+    // downward spreading, Kabal (28): E2[i-1] = aLe E2[i] + Ene[i-1]  (suffix scan)
+    double dn0, dn1;
+    {
+      const double al = bt->aLe;
+      const double v = wave_suffix_geometric(ene[0] + al * ene[1], al * al, lane);   // pair-local, then over the lanes
+      const double nxt = lane_above(v);                // E2down[2 lane + 2]; 0 beyond the last lane
+      dn0 = v;
+      dn1 = ene[1] + al * nxt;
+    }
+    wave_lds_fence();
+    // (25): the excitation is E2^(1/0.4) / normalisation; the record carries E2^(1/4), from which the back
+    // end gets E and E^0.3 by multiplications (excitation_from_root, peaq_device.h)
+    double root[2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const double e2 = (s ? dn1 : dn0) + e2up[128 * s + lane];   // band 2 lane + s
-    root[s] = b0 + s < NB ? sqrt_pos(sqrt_pos(e2)) : 0.;
-  }
-  if (b0 < kBandStride)
-    *reinterpret_cast<double2*>(rec + (sig ? kRecRootTest : kRecRootRef) + b0) = make_double2(root[0], root[1]);
+    for (int s = 0; s < 2; ++s) {
+      const double e2 = (s ? dn1 : dn0) + e2up[128 * s + lane];   // band 2 lane + s
+      root[s] = b0 + s < NB ? sqrt_pos(sqrt_pos(e2)) : 0.;
+    }
+    if (b0 < kBandStride)
+      *reinterpret_cast<double2*>(rec + (sig ? kRecRootTest : kRecRootRef) + b0) = make_double2(root[0], root[1]);
 
+  }
   FE_MARK(6);                                        // downward spreading, excitation, record
   __syncthreads();                                   // both spectra are in LDS
   FE_MARK(7);                                        // barrier

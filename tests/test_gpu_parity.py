@@ -72,14 +72,24 @@ def test_frontend_records_match_oracle(gpu, bands, case):
     got = gstpeaq_amd.debug_frontend(gpu.ctx(), bands, torch.from_numpy(ref).cuda(), torch.from_numpy(test).cuda(),
                                      n_frames)
     exp = oracle_records(bands, ref, test, n_frames)
-    for name, lo in (("unsm_ref", 0), ("unsm_test", 112), ("loud_ref", 224), ("loud_test", 336)):
+    # The 55-band kernel is the advanced version's FFT path: that version reads neither the test signal's
+    # excitation nor the bandwidths (process_fft_block_advanced, gstpeaq.c:924-959), so the kernel does
+    # not compute them and the record carries zeros there.
+    fields = (("unsm_ref", 0), ("unsm_test", 112), ("loud_ref", 224), ("loud_test", 336))
+    for name, lo in fields:
+        if bands == 55 and name.endswith("_test"):
+            assert not got[:, :, lo:lo + bands].any(), name
+            continue
         np.testing.assert_allclose(got[:, :, lo:lo + bands], exp[:, :, lo:lo + bands], rtol=2e-10, atol=0,
                                    err_msg=name)
     # noise = Pr - 2 sqrt(Pr Pt) + Pt cancels heavily where the signals are close: the rounding of
     # the two DFT implementations (kissfft-like radix-2 in the oracle, 16x16x4 Stockham here) shows
     np.testing.assert_allclose(got[:, :, 448:448 + bands], exp[:, :, 448:448 + bands], rtol=1e-6, atol=0,
                                err_msg="noise")
-    assert np.array_equal(got[:, :, 560:562], exp[:, :, 560:562]), "bandwidths"
+    if bands == 109:
+        assert np.array_equal(got[:, :, 560:562], exp[:, :, 560:562]), "bandwidths"
+    else:
+        assert not got[:, :, 560:562].any(), "bandwidths (not computed by the advanced version)"
     assert np.array_equal(got[:, :, 563:565], exp[:, :, 563:565]), "flags"
     # EHS: the oracle goes through 512-point FFTs like the reference, the kernel sums directly
     assert np.array_equal(np.isnan(got[:, :, 562]), np.isnan(exp[:, :, 562]))
