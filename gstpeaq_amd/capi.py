@@ -18,6 +18,13 @@ RESULT_DOUBLES = 16
 RECORD_DOUBLES = 576
 
 
+class Settings(C.Structure):
+    """mirrors peaq_settings (include/peaq_amd.h): the reference's settings.h switches"""
+    _fields_ = [("swap_mod_patts_for_noise_loudness_movs", C.c_int), ("center_ehs_correlation_window", C.c_int),
+                ("ehs_subtract_dc_before_window", C.c_int), ("use_floor_for_steps_above_threshold", C.c_int),
+                ("clamp_movs", C.c_int), ("swap_slope_filter_coefficients", C.c_int)]
+
+
 class PeaqError(RuntimeError):
     pass
 
@@ -76,6 +83,10 @@ def load_library():
     L.peaq_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.peaq_ctx_destroy.argtypes = [vp]
     L.peaq_ctx_device.argtypes = [vp]
+    L.peaq_settings_default.restype = None
+    L.peaq_settings_default.argtypes = [C.POINTER(Settings)]
+    L.peaq_ctx_set_settings.argtypes = [vp, C.POINTER(Settings)]
+    L.peaq_ctx_get_settings.argtypes = [vp, C.POINTER(Settings)]
     L.peaq_ctx_set_fir_fp64.argtypes = [vp, C.c_int]
     L.peaq_ctx_get_fir_fp64.argtypes = [vp]
     L.peaq_session_create.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.POINTER(vp)]
@@ -142,6 +153,23 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_settings(self, **changed):
+        """the reference's settings.h switches by name (include/peaq_amd.h peaq_settings); unnamed ones get
+        the shipped values, no argument restores all of them.  Applies to batch calls made and to sessions /
+        brokers created afterwards."""
+        st = Settings()
+        self.L.peaq_settings_default(C.byref(st))
+        for k, v in changed.items():
+            if k not in dict(Settings._fields_):
+                raise PeaqError(f"unknown setting {k}")
+            setattr(st, k, int(v))
+        _check(self.L.peaq_ctx_set_settings(self.h, C.byref(st)))
+
+    def settings(self):
+        st = Settings()
+        _check(self.L.peaq_ctx_get_settings(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in Settings._fields_}
 
     def set_fir_fp64(self, enable):
         """advanced version: FIR bank on the FP64 matrix instruction (default: FP32, see include/peaq_amd.h)"""

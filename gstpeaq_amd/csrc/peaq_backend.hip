@@ -541,7 +541,7 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
           const double x = div_fast(e, sd), x2 = x * x;
           const double xb = er_db > et_db ? x2 * x2 : x2 * x2 * x2;   // (e/s)^b, b = 4 or 6
           pc = 1. - be_exp(-kLn2 * xb);                             // 1 - 0.5^((e/s)^b)
-          qc = div_fast(fabs(trunc(e)), sd);
+          qc = div_fast(fabs(a.cfg.floor_steps ? floor(e) : trunc(e)), sd);   // movs.c:1256-1260
         }
         sh.pc[chan][bl.band(s)] = pc;
         sh.qc[chan][bl.band(s)] = qc;
@@ -790,11 +790,14 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
       }
     }
     if (blk >= 125 && blk - 13 >= loud_reached) {    // gstpeaq.c:996-1007
-      // movs.c:551-577 with SWAP_MOD_PATTS_FOR_NOISE_LOUDNESS_MOVS 1
+      // movs.c:551-577; SWAP_MOD_PATTS_FOR_NOISE_LOUDNESS_MOVS (shipped: 1) exchanges the modulation
+      // patterns of the missing-components term ...
+      const bool swap = a.cfg.swap_mod_patts != 0;   // workgroup-uniform
       const double nl = noise_loudness<NB, SLOTS>(bl, bt, 2.5, 0.3, 1., 0.1, mr, mt, ad_ref, ad_test);
-      const double mc = noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 1., 0., mt, mr, ad_test, ad_ref);
-      // movs.c:679-706 (same switch): reference modulation twice, unadapted FB excitation
-      const double ld = noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 1., 0., mr, mr, ad_ref, er);
+      const double mc = noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 1., 0., swap ? mt : mr, swap ? mr : mt, ad_test,
+                                                  ad_ref);
+      // ... and (movs.c:679-706) takes the reference modulation twice; unadapted FB excitation
+      const double ld = noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 1., 0., mr, swap ? mr : mt, ad_ref, er);
       if (lane == MA_NLASYM) {
         v0 = nl;
         w0 = mc;
@@ -887,7 +890,7 @@ __constant__ double na_wxb[5] = {1.330890, 2.686103, 2.096598, -1.327851, 3.0870
 __constant__ double na_wy[5] = {-4.696996, -3.289959, 7.004782, 6.651897, 4.009144};
 
 __global__ void finalize_kernel(const PairState* __restrict__ st, int advanced, int channels, unsigned n_pairs,
-                                ResultRecord* __restrict__ out) {
+                                ResultRecord* __restrict__ out, int clamp_movs) {
   const unsigned pair = blockIdx.x * blockDim.x + threadIdx.x;
   if (pair >= n_pairs) return;
   const PairState* ps = st + pair;
@@ -907,7 +910,8 @@ __global__ void finalize_kernel(const PairState* __restrict__ st, int advanced, 
   if (!advanced) {
     double x[3] = {nb_wxb[0], nb_wxb[1], nb_wxb[2]};
     for (int i = 0; i < 11; ++i) {
-      const double m = (r.movs[i] - nb_amin[i]) / (nb_amax[i] - nb_amin[i]);   // CLAMP_MOVS 0
+      double m = (r.movs[i] - nb_amin[i]) / (nb_amax[i] - nb_amin[i]);
+      if (clamp_movs) m = m < 0. ? 0. : m > 1. ? 1. : m;                 // CLAMP_MOVS, nn.c:202-207
       for (int j = 0; j < 3; ++j) x[j] += nb_wx[i][j] * m;
     }
     di = -0.307594;
@@ -916,7 +920,8 @@ __global__ void finalize_kernel(const PairState* __restrict__ st, int advanced, 
     double x[5];
     for (int j = 0; j < 5; ++j) x[j] = na_wxb[j];
     for (int i = 0; i < 5; ++i) {
-      const double m = (r.movs[i] - na_amin[i]) / (na_amax[i] - na_amin[i]);
+      double m = (r.movs[i] - na_amin[i]) / (na_amax[i] - na_amin[i]);
+      if (clamp_movs) m = m < 0. ? 0. : m > 1. ? 1. : m;                 // nn.c:320-325
       for (int j = 0; j < 5; ++j) x[j] += na_wx[i][j] * m;
     }
     di = -1.360308;
@@ -931,10 +936,10 @@ __global__ void finalize_kernel(const PairState* __restrict__ st, int advanced, 
 }
 
 hipError_t launch_finalize(const PairState* state, int advanced, int channels, unsigned n_pairs, ResultRecord* out,
-                           hipStream_t stream) {
+                           hipStream_t stream, const Settings& cfg) {
   if (n_pairs == 0) return hipSuccess;
   hipLaunchKernelGGL(finalize_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, stream, state, advanced, channels,
-                     n_pairs, out);
+                     n_pairs, out, cfg.clamp_movs);
   return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <condition_variable>
 #include <cmath>
@@ -130,6 +131,7 @@ struct peaq_ctx {
   size_t events_used = 0;
   unsigned long long* d_prof = nullptr;   // -DPEAQ_FE_PROFILE builds only
   int fir_fp64 = 0;                       // advanced version: FIR bank on the FP64 instead of the FP32 matrix instruction
+  Settings settings;                      // the reference's settings.h switches (peaq_ctx_set_settings)
 
   hipEvent_t next_event() {
     if (events_used == event_pool.size()) {
@@ -156,6 +158,37 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
   {
     const char* e = std::getenv("PEAQ_AMD_FIR_FP64");
     c->fir_fp64 = e && *e && *e != '0';
+  }
+  if (const char* e = std::getenv("PEAQ_AMD_SETTINGS")) {
+    // "CLAMP_MOVS=1,center_ehs_correlation_window=1": the settings.h macro names, any case -- lets the CLI and
+    // the element (which have no such property, like the reference's) run the other readings of BS.1387
+    struct { const char* name; int* field; } tab[] = {
+        {"swap_mod_patts_for_noise_loudness_movs", &c->settings.swap_mod_patts},
+        {"center_ehs_correlation_window", &c->settings.centre_ehs_window},
+        {"ehs_subtract_dc_before_window", &c->settings.ehs_dc_before_window},
+        {"use_floor_for_steps_above_threshold", &c->settings.floor_steps},
+        {"clamp_movs", &c->settings.clamp_movs},
+        {"swap_slope_filter_coefficients", &c->settings.swap_slope}};
+    std::string spec(e);
+    size_t pos = 0;
+    while (pos < spec.size()) {
+      const size_t end = std::min(spec.find(',', pos), spec.size());
+      std::string item = spec.substr(pos, end - pos);
+      pos = end + 1;
+      const size_t eq = item.find('=');
+      std::string key = item.substr(0, eq);
+      for (char& ch : key) ch = (char)std::tolower((unsigned char)ch);
+      bool known = false;
+      for (auto& t : tab)
+        if (key == t.name) {
+          *t.field = eq != std::string::npos && std::atoi(item.c_str() + eq + 1) != 0;
+          known = true;
+        }
+      if (!known && !item.empty()) {
+        delete c;
+        return fail(PEAQ_ERR_ARG, "PEAQ_AMD_SETTINGS: unknown switch '" + item + "' (settings.h macro names, NAME=0|1)");
+      }
+    }
   }
   const int rc = [&]() -> int {
   {
@@ -244,6 +277,43 @@ extern "C" int peaq_ctx_set_fir_fp64(peaq_ctx* c, int enable) {
 }
 extern "C" int peaq_ctx_get_fir_fp64(const peaq_ctx* c) { return c ? c->fir_fp64 : -1; }
 
+extern "C" void peaq_settings_default(peaq_settings* s) {
+  if (!s) return;
+  const Settings d;
+  s->swap_mod_patts_for_noise_loudness_movs = d.swap_mod_patts;
+  s->center_ehs_correlation_window = d.centre_ehs_window;
+  s->ehs_subtract_dc_before_window = d.ehs_dc_before_window;
+  s->use_floor_for_steps_above_threshold = d.floor_steps;
+  s->clamp_movs = d.clamp_movs;
+  s->swap_slope_filter_coefficients = d.swap_slope;
+}
+
+extern "C" int peaq_ctx_set_settings(peaq_ctx* c, const peaq_settings* s) {
+  if (!c) return fail(PEAQ_ERR_ARG, "peaq_ctx_set_settings: ctx is NULL");
+  peaq_settings d;
+  peaq_settings_default(&d);
+  if (!s) s = &d;                                    // NULL: back to the reference's shipped values
+  std::lock_guard<std::mutex> lock(c->mu);
+  c->settings.swap_mod_patts = s->swap_mod_patts_for_noise_loudness_movs != 0;
+  c->settings.centre_ehs_window = s->center_ehs_correlation_window != 0;
+  c->settings.ehs_dc_before_window = s->ehs_subtract_dc_before_window != 0;
+  c->settings.floor_steps = s->use_floor_for_steps_above_threshold != 0;
+  c->settings.clamp_movs = s->clamp_movs != 0;
+  c->settings.swap_slope = s->swap_slope_filter_coefficients != 0;
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_ctx_get_settings(const peaq_ctx* c, peaq_settings* s) {
+  if (!c || !s) return fail(PEAQ_ERR_ARG, "peaq_ctx_get_settings: NULL argument");
+  s->swap_mod_patts_for_noise_loudness_movs = c->settings.swap_mod_patts;
+  s->center_ehs_correlation_window = c->settings.centre_ehs_window;
+  s->ehs_subtract_dc_before_window = c->settings.ehs_dc_before_window;
+  s->use_floor_for_steps_above_threshold = c->settings.floor_steps;
+  s->clamp_movs = c->settings.clamp_movs;
+  s->swap_slope_filter_coefficients = c->settings.swap_slope;
+  return PEAQ_OK;
+}
+
 #ifdef PEAQ_FE_PROFILE
 // development builds only: reads and clears the front end's phase counters (tools/fe_profile.py)
 extern "C" int peaq_debug_frontend_profile(peaq_ctx* c, unsigned long long* out64) {
@@ -331,6 +401,7 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
     HIP_TRY(c->fbstate.reserve((size_t)n_signals * sizeof(FbSignalState)));
     HIP_TRY(hipMemsetAsync(c->fbstate.p, 0, (size_t)n_signals * sizeof(FbSignalState), stream));
     FbFrontArgs ff{};
+    ff.cfg = c->settings;
     ff.fir_fp64 = c->fir_fp64;
     ff.ref = d_ref;
     ff.test = d_test;
@@ -348,6 +419,7 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
     ff.fbstate = c->fbstate.as<FbSignalState>();
     ff.hp_row_stride = row_stride;
     FbBackendArgs fbk{};
+    fbk.cfg = c->settings;
     fbk.n_blocks = d_nblocks;
     fbk.n_blocks_uniform = max_blocks;
     fbk.channels = channels;
@@ -512,6 +584,7 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
   }
 
   FrontendArgs fa{};
+  fa.cfg = c->settings;
   fa.ref = d_ref;
   fa.test = d_test;
   fa.pair_stride = pair_stride;
@@ -530,6 +603,7 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
   fa.bands = advanced ? c->d_bands55 : c->d_bands109;    // gstpeaq.c:521-526
   fa.prof = c->d_prof;
   BackendArgs ba{};
+  ba.cfg = c->settings;
   ba.n_frames = d_nframes;
   ba.n_frames_uniform = max_frames;
   ba.channels = channels;
@@ -570,7 +644,7 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
     if (back_done[i]) HIP_TRY(hipStreamWaitEvent(stream, back_done[i], 0));
   if (fb_done) HIP_TRY(hipStreamWaitEvent(stream, fb_done, 0));
   HIP_TRY(launch_finalize(c->state.as<PairState>(), advanced, channels, n_pairs,
-                          reinterpret_cast<ResultRecord*>(d_results), stream));
+                          reinterpret_cast<ResultRecord*>(d_results), stream, c->settings));
   HIP_TRY(hipEventRecord(c->batch_end, stream));
   c->batch_pending = true;
   return PEAQ_OK;
@@ -638,6 +712,7 @@ extern "C" int peaq_debug_frontend(peaq_ctx* c, int bands, int channels, double 
   uint32_t* d_n = n_buf.as<uint32_t>();
   HIP_TRY(hipMemcpy(d_n, h_n, sizeof h_n, hipMemcpyHostToDevice));
   FrontendArgs fa{};
+  fa.cfg = c->settings;
   fa.ref = d_ref;
   fa.test = d_test;
   fa.pair_stride = std::max(n_ref, n_test);
@@ -693,6 +768,7 @@ extern "C" int peaq_debug_filterbank(peaq_ctx* c, int channels, double level_db,
   HIP_TRY(st.reserve(n_signals * sizeof(FbSignalState)));
   HIP_TRY(hipMemset(st.p, 0, n_signals * sizeof(FbSignalState)));
   FbFrontArgs ff{};
+  ff.cfg = c->settings;
   ff.fir_fp64 = c->fir_fp64;
   ff.ref = d_ref;
   ff.test = d_test;
@@ -762,6 +838,7 @@ extern "C" int peaq_debug_backend(peaq_ctx* c, int channels, int n_frames, const
   HIP_TRY(hipMemset(dbg.p, 0, dbg_bytes));
   HIP_TRY(launch_state_init(st.as<PairState>(), 0, 1, nullptr));
   BackendArgs ba{};
+  ba.cfg = c->settings;
   ba.records = recs.as<double>();
   ba.frame0 = 0;
   ba.frames_per_launch = n_frames;
@@ -772,7 +849,7 @@ extern "C" int peaq_debug_backend(peaq_ctx* c, int channels, int n_frames, const
   ba.state = st.as<PairState>();
   ba.debug = dbg.as<double>();
   HIP_TRY(launch_backend(ba, 1, nullptr));
-  HIP_TRY(launch_finalize(st.as<PairState>(), 0, channels, 1, res.as<ResultRecord>(), nullptr));
+  HIP_TRY(launch_finalize(st.as<PairState>(), 0, channels, 1, res.as<ResultRecord>(), nullptr, c->settings));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(host_out, dbg.p, dbg_bytes, hipMemcpyDeviceToHost));
   if (result) HIP_TRY(hipMemcpy(result, res.p, sizeof(peaq_result), hipMemcpyDeviceToHost));
@@ -820,6 +897,7 @@ struct peaq_session {
   peaq_ctx* ctx = nullptr;
   int advanced = 0, channels = 1;
   double level_db = 92.;
+  Settings cfg;                     // the context's settings when the session was created
   std::mutex mu;
   PadFifo pad[2];
   uint64_t fft_pos[2] = {0, 0};   // stream sample where the next FFT frame starts, per pad
@@ -870,6 +948,7 @@ extern "C" int peaq_session_create(peaq_ctx* c, int advanced, int channels, doub
   peaq_session* s = new (std::nothrow) peaq_session;
   if (!s) return fail(PEAQ_ERR_NOMEM, "out of host memory");
   s->ctx = c;
+  s->cfg = c->settings;
   s->advanced = advanced ? 1 : 0;
   s->channels = channels;
   s->level_db = level_db;
@@ -929,6 +1008,7 @@ static int session_run_frames(peaq_session* s, unsigned nf, const uint64_t n_val
     if (rc != PEAQ_OK) return rc;
   }
   FrontendArgs fa{};
+  fa.cfg = s->cfg;
   fa.ref = s->d_sig[0].as<float>();
   fa.test = s->d_sig[1].as<float>();
   fa.pair_stride = s->stage_samples;
@@ -945,6 +1025,7 @@ static int session_run_frames(peaq_session* s, unsigned nf, const uint64_t n_val
   fa.records = s->records.as<double>();
   HIP_TRY(launch_frontend(s->advanced ? 55 : 109, fa, 1, s->stream));
   BackendArgs ba{};
+  ba.cfg = s->cfg;
   ba.records = fa.records;
   ba.frame0 = s->frames_done;
   ba.frames_per_launch = nf;
@@ -966,6 +1047,7 @@ static int session_run_blocks(peaq_session* s, unsigned nb, const uint64_t n_val
     if (rc != PEAQ_OK) return rc;
   }
   FbFrontArgs ff{};
+  ff.cfg = s->cfg;
   ff.fir_fp64 = c->fir_fp64;
   ff.ref = s->d_sig[0].as<float>();
   ff.test = s->d_sig[1].as<float>();
@@ -988,6 +1070,7 @@ static int session_run_blocks(peaq_session* s, unsigned nb, const uint64_t n_val
   ff.records = s->fb_records.as<double>();
   HIP_TRY(launch_fb_frontend(ff, 1, s->stream));
   FbBackendArgs fbk{};
+  fbk.cfg = s->cfg;
   fbk.records = ff.records;
   fbk.block0 = s->blocks_done;
   fbk.blocks_per_launch = nb;
@@ -1089,7 +1172,7 @@ extern "C" int peaq_session_results(peaq_session* s, peaq_result* out) {
   std::lock_guard<std::mutex> lock(s->mu);
   HIP_TRY(hipSetDevice(s->ctx->device));
   HIP_TRY(launch_finalize(s->state.as<PairState>(), s->advanced, s->channels, 1, s->result.as<ResultRecord>(),
-                          s->stream));
+                          s->stream, s->cfg));
   HIP_TRY(hipMemcpyAsync(out, s->result.p, sizeof(peaq_result), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return PEAQ_OK;
@@ -1272,6 +1355,7 @@ struct peaq_broker {
   peaq_ctx* ctx = nullptr;
   int advanced = 0, channels = 1;
   double level_db = 92.;
+  Settings cfg;                     // the context's settings when the broker was created
   int max_sessions = 0;
   std::vector<BrokerSlot*> slots;
   std::mutex tick_mu;               // one tick at a time; guards everything below
@@ -1433,6 +1517,7 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
       HIP_TRY(hipMemcpyAsync(b->fft.d[p].p, b->fft.h[p], active * stride * sizeof(float), hipMemcpyHostToDevice,
                              b->stream));
     FrontendArgs fa{};
+    fa.cfg = b->cfg;
     fa.ref = b->fft.d[0].as<float>();
     fa.test = b->fft.d[1].as<float>();
     fa.pair_stride = b->fft.samples;
@@ -1448,6 +1533,7 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
     fa.records = b->records.as<double>();
     HIP_TRY(launch_frontend(b->advanced ? 55 : 109, fa, active, b->stream));
     BackendArgs ba{};
+    ba.cfg = b->cfg;
     ba.records = fa.records;
     ba.frames_per_launch = max_nf;
     ba.channels = b->channels;
@@ -1466,6 +1552,7 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
                              b->stream));
     HIP_TRY(hipMemcpyAsync(b->d_win.p, b->h_win, fb_active * sizeof(FbPairWindow), hipMemcpyHostToDevice, b->stream));
     FbFrontArgs ff{};
+    ff.cfg = b->cfg;
     ff.fir_fp64 = c->fir_fp64;
     ff.ref = b->fbs.d[0].as<float>();
     ff.test = b->fbs.d[1].as<float>();
@@ -1484,6 +1571,7 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
     ff.windows = b->d_win.as<FbPairWindow>();
     HIP_TRY(launch_fb_frontend(ff, fb_active, b->stream));
     FbBackendArgs fbk{};
+    fbk.cfg = b->cfg;
     fbk.records = ff.records;
     fbk.blocks_per_launch = max_nb;
     fbk.channels = b->channels;
@@ -1533,6 +1621,7 @@ extern "C" int peaq_broker_create(peaq_ctx* c, int advanced, int channels, doubl
   peaq_broker* b = new (std::nothrow) peaq_broker;
   if (!b) return fail(PEAQ_ERR_NOMEM, "out of host memory");
   b->ctx = c;
+  b->cfg = c->settings;
   b->advanced = advanced ? 1 : 0;
   b->channels = channels;
   b->level_db = level_db;
@@ -1736,7 +1825,7 @@ extern "C" int peaq_broker_results(peaq_broker* b, int session_id, peaq_result* 
   }
   HIP_TRY(hipSetDevice(b->ctx->device));
   HIP_TRY(launch_finalize(b->state.as<PairState>() + session_id, b->advanced, b->channels, 1,
-                          b->result.as<ResultRecord>(), b->stream));
+                          b->result.as<ResultRecord>(), b->stream, b->cfg));
   HIP_TRY(hipMemcpyAsync(out, b->result.p, sizeof(peaq_result), hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
   return PEAQ_OK;

@@ -48,6 +48,7 @@ struct CommonTables {
   double tw_lane[8][64][2];
   double ear_w2_pair[8][64][2]; // ear_w2 of bin l + 64 q and of its mirror bin (spec_bin(8 + q, l)), q = 0..7
   double ehs_window[256];       // movs.c:1366-1367
+  double ehs_window_centred[256];   // movs.c:1363-1364 (CENTER_EHS_CORRELATION_WINDOW)
 };
 
 struct BandTables {             // earmodel.c:279-323 + fftearmodel.c:693-788
@@ -91,6 +92,17 @@ struct FbTables {               // fbearmodel.c:57-61,182-225
 };
 
 // ---- per-frame record: front end -> back end --------------------------------
+// The reference's compile-time readings of BS.1387 (settings.h:47-97) as run-time switches; the defaults
+// are the values the reference ships with (include/peaq_amd.h, peaq_settings).
+struct Settings {
+  int swap_mod_patts = 1;        // SWAP_MOD_PATTS_FOR_NOISE_LOUDNESS_MOVS   (movs.c:566-575, 693-703)
+  int centre_ehs_window = 0;     // CENTER_EHS_CORRELATION_WINDOW            (movs.c:1362-1368)
+  int ehs_dc_before_window = 1;  // EHS_SUBTRACT_DC_BEFORE_WINDOW            (movs.c:1409-1433)
+  int floor_steps = 0;           // USE_FLOOR_FOR_STEPS_ABOVE_THRESHOLD      (movs.c:1256-1260)
+  int clamp_movs = 0;            // CLAMP_MOVS                               (nn.c:202-207, 320-325)
+  int swap_slope = 0;            // SWAP_SLOPE_FILTER_COEFFICIENTS           (fbearmodel.c:335-339)
+};
+
 // One record per (pair, frame, channel), kRecDoubles doubles: what the stateless front end hands to the
 // back end.  The excitation travels as ONE number per band and signal, root = E2^(1/4) of the spread band
 // energy E2 (fftearmodel.c:556-597): the unsmeared excitation E = E2^2.5 / norm and E^0.3 (modpatt.c:235)

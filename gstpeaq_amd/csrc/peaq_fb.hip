@@ -554,9 +554,12 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
     for (int i = 0; i < 10; ++i) sh.hist[tid][i] = st->e0_hist[tid][i];
   }
   double exc = tid < kFbBands ? st->excitation[tid] : 0.;
-  // (1-A)^(t+1): decay of the slope-filter state that enters a tile; (1-A)^((t & 15) + 1) for the row carries
-  auto pow_1ma = [](int e) {
-    double p = 1. - kSlopeA, acc = 1.;
+  // Slope filter (fbearmodel.c:335-339): cu_t = m cu_(t-1) + g dist_t with (m, g) = (1 - A, A) as the
+  // pseudo code of BS.1387 has it (shipped), or (A, 1 - A) with SWAP_SLOPE_FILTER_COEFFICIENTS.
+  // m^(t+1): decay of the state that enters a tile; m^((t & 15) + 1) for the row carries of the scan
+  const double sm = a.cfg.swap_slope ? kSlopeA : 1. - kSlopeA, sg = a.cfg.swap_slope ? 1. - kSlopeA : kSlopeA;
+  auto pow_m = [sm](int e) {
+    double p = sm, acc = 1.;
     while (e) {
       if (e & 1) acc *= p;
       p *= p;
@@ -564,8 +567,8 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
     }
     return acc;
   };
-  const double decay = pow_1ma(lane + 1), decay_row = pow_1ma((lane & 15) + 1);
-  constexpr double kM1 = 1. - kSlopeA, kM2 = kM1 * kM1, kM4 = kM2 * kM2, kM8 = kM4 * kM4, kM16 = kM8 * kM8;
+  const double decay = pow_m(lane + 1), decay_row = pow_m((lane & 15) + 1);
+  const double kM1 = sm, kM2 = kM1 * kM1, kM4 = kM2 * kM2, kM8 = kM4 * kM4, kM16 = kM8 * kM8;
 
   constexpr double kC1 = -2. * kLnDist / 2.302585092994046;         // -0.2 * 10 / ln 10 * ln DIST
   double c0[10];
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       // pow(DIST, s), s = max(4, 24 + 230/fc - 0.2 L), L = 10 log10 |A|^2 (fbearmodel.c:329-333), as
       // exp(min(4 ln DIST, ln DIST (24 + 230/fc) - 2 ln DIST / ln 10 * ln |A|^2))  (ln DIST < 0)
       const double dist_s = exp_fast(fmin(4. * kLnDist, c0[i] + kC1 * log_nonneg(re[i] * re[i] + im[i] * im[i])));
-      const double v = wave_prefix_geometric(kSlopeA * dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
+      const double v = wave_prefix_geometric(sg * dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
       const double cu = v + decay * sh.cu[b];
       const double carry = __shfl(cu, nvs - 1, 64);
       if (lane == 0) sh.cu[b] = carry;                               // only this wave touches cu[b]

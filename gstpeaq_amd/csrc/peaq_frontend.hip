@@ -842,13 +842,17 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
       c[m] *= rsqrt_pos(d0 * d[lane + 64 * m]);      // NaN when d0 = 0 (identical signals), as in the reference
       cavg += c[m];
     }
-    cavg = wave_sum(cavg) / 256.;
-    // mean removed before windowing (EHS_SUBTRACT_DC_BEFORE_WINDOW 1), 256-point DFT
+    // the mean is removed before the window (the shipped EHS_SUBTRACT_DC_BEFORE_WINDOW, movs.c:1409-1421) or
+    // as the DC bin after the transform (:1429-1433); the window is the one of :1366-1367 or the centred
+    // one of :1363-1364 (settings.h:56, 66 as run-time switches)
+    cavg = a.cfg.ehs_dc_before_window ? wave_sum(cavg) / 256. : 0.;
+    const double* __restrict__ win = a.cfg.centre_ehs_window ? ct->ehs_window_centred : ct->ehs_window;
     cplx w4[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) w4[m] = {(c[m] - cavg) * ct->ehs_window[lane + 64 * m], 0.};
+    for (int m = 0; m < 4; ++m) w4[m] = {(c[m] - cavg) * win[lane + 64 * m], 0.};
     wave_lds_fence();
     fft256(w4);
+    if (!a.cfg.ehs_dc_before_window && lane == 0) w4[0].re = 0.;   // bin 0 sits in slot 0 of lane 0
     // w4[r] = C[lane + 64 r]; EHS = highest |C|^2 that exceeds its left neighbour, bins 1..128
     const double s0 = w4[0].re * w4[0].re + w4[0].im * w4[0].im;
     const double s1 = w4[1].re * w4[1].re + w4[1].im * w4[1].im;

@@ -38,6 +38,7 @@ struct FrontendArgs {
   const uint32_t* pair_nframes;
   // -DPEAQ_FE_PROFILE builds only (tools/fe_profile.py): [2 waves][16 phases] cycle sums + [32] wave count
   unsigned long long* prof;
+  Settings cfg;                 // centre_ehs_window, ehs_dc_before_window
 };
 hipError_t launch_frontend(int bands, const FrontendArgs& a, unsigned n_pairs, hipStream_t stream);
 
@@ -56,6 +57,7 @@ struct BackendArgs {
   const uint32_t* pair_nframes;
   const uint32_t* pair_slot;    // state index of pair p (nullptr: p)
   double* debug;                // basic version only: [pair][frame - frame0][channel][kDbgDoubles], or nullptr
+  Settings cfg;                 // floor_steps
 };
 hipError_t launch_backend(const BackendArgs& a, unsigned n_pairs, hipStream_t stream);
 
@@ -65,7 +67,7 @@ struct ResultRecord {           // mirrors peaq_result in include/peaq_amd.h
   double di, odg, totalsnr, frames, fb_blocks;
 };
 hipError_t launch_finalize(const PairState* state, int advanced, int channels, unsigned n_pairs,
-                           ResultRecord* out, hipStream_t stream);
+                           ResultRecord* out, hipStream_t stream, const Settings& cfg = Settings());   // clamp_movs
 hipError_t launch_state_init(PairState* state, int advanced, unsigned n_pairs, hipStream_t stream);
 
 // ---- advanced mode: filter-bank ear model ------------------------------------------
@@ -102,6 +104,7 @@ struct FbFrontArgs {
   size_t hp_row_stride;
   double* records;              // [pair][block - block0][channel][kFbRecDoubles]
   const FbPairWindow* windows;  // broker launches (see above); nullptr: the uniform fields apply, slot = pair
+  Settings cfg;                 // swap_slope
   int fir_fp64;                 // 1: FIR bank on v_mfma_f64 (exact to the oracle's 1e-9); 0: v_mfma_f32 (default, see peaq_fb.hip)
 };
 hipError_t launch_fb_frontend(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream);   // high-pass + filter bank
@@ -117,6 +120,7 @@ struct FbBackendArgs {
   const BandTables* bands;
   PairState* state;
   const FbPairWindow* windows;  // broker launches
+  Settings cfg;                 // swap_mod_patts
 };
 hipError_t launch_fb_backend(const FbBackendArgs& a, unsigned n_pairs, hipStream_t stream);
 

@@ -240,8 +240,10 @@ void build_common_tables(CommonTables& c) {
         c.ear_w2_pair[q][l][1] = c.ear_w2[km];
       }
   }
-  for (int i = 0; i < 256; ++i)  // CENTER_EHS_CORRELATION_WINDOW 0
+  for (int i = 0; i < 256; ++i) {  // movs.c:1362-1368: the shipped window, and the one centred at lag zero
     c.ehs_window[i] = 0.81649658092773 * (1.0 - std::cos(2 * kPi * i / 255.0)) / 256.0;
+    c.ehs_window_centred[i] = 0.81649658092773 * (1.0 + std::cos(2 * kPi * i / 511.0)) / 256.0;
+  }
 }
 
 double fft_level_factor(double level_db) {

@@ -69,6 +69,25 @@ typedef struct peaq_ctx peaq_ctx;
 int peaq_ctx_create (int device_ordinal, peaq_ctx **out);
 void peaq_ctx_destroy (peaq_ctx *ctx);
 int peaq_ctx_device (const peaq_ctx *ctx);
+/* ---- the reference's readings of BS.1387 as run-time switches ---------------
+ * The reference is compiled with ONE value for each of six interpretation
+ * switches (src/settings.h:47-97); a context carries them as data.  The
+ * defaults (peaq_settings_default, or passing NULL) are the values the reference
+ * ships with, and every golden of the default build pins exactly those.
+ * A change applies to batch calls made, and to sessions and brokers CREATED,
+ * afterwards.  Each field replaces the settings.h macro of the same name. */
+typedef struct peaq_settings {
+  int swap_mod_patts_for_noise_loudness_movs;   /* settings.h:47  default 1  (movs.c:566-575, 693-703) */
+  int center_ehs_correlation_window;            /* settings.h:56  default 0  (movs.c:1362-1368) */
+  int ehs_subtract_dc_before_window;            /* settings.h:66  default 1  (movs.c:1409-1433) */
+  int use_floor_for_steps_above_threshold;      /* settings.h:76  default 0  (movs.c:1256-1260) */
+  int clamp_movs;                               /* settings.h:86  default 0  (nn.c:202-207, 320-325) */
+  int swap_slope_filter_coefficients;           /* settings.h:97  default 0  (fbearmodel.c:335-339) */
+} peaq_settings;
+void peaq_settings_default (peaq_settings *s);
+int peaq_ctx_set_settings (peaq_ctx *ctx, const peaq_settings *s);
+int peaq_ctx_get_settings (const peaq_ctx *ctx, peaq_settings *s);
+
 /* Advanced version only: which matrix instruction evaluates the 40 complex FIR filters of the
  * filter-bank ear model (fbearmodel.c:399-435).  Default 0 = FP32 (v_mfma_f32_16x16x4_f32, twice the
  * rate): measured max |dODG| against the all-FP64 path 5e-8 over 39 advanced cases

@@ -16,6 +16,21 @@
 #include <string.h>
 #include <limits.h>
 
+/* The reference's compile-time readings of BS.1387 (settings.h:47-97) as run-time values, in the order
+ * of that header; the defaults are the values the reference ships with. */
+static int orc_cfg[6] = { 1, 0, 1, 0, 0, 0 };
+enum { CFG_SWAP_MOD_PATTS, CFG_CENTER_EHS_WINDOW, CFG_EHS_DC_BEFORE_WINDOW, CFG_FLOOR_STEPS, CFG_CLAMP_MOVS,
+       CFG_SWAP_SLOPE };
+
+void
+orc_set_settings (const int *six)
+{
+  int i;
+  for (i = 0; i < 6; i++)
+    orc_cfg[i] = six ? six[i] : (i == 0 || i == 2);
+}
+
+
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
@@ -409,7 +424,10 @@ orc_fbmodel_process (const orc_fbmodel *m, orc_fbstate *s, const float *x)
         double slope = MAXF (4, 24 + 230 / m->b.fc[band] - 0.2 * level);
         double dist_s = pow (FB_DIST, slope);
         double d1 = fr[band], d2 = fi[band];
-        s->cu[band] = s->cu[band] + FB_SLOPE_A * (dist_s - s->cu[band]);
+        if (orc_cfg[CFG_SWAP_SLOPE])            /* fbearmodel.c:335-339 */
+          s->cu[band] = dist_s + FB_SLOPE_A * (s->cu[band] - dist_s);
+        else
+          s->cu[band] = s->cu[band] + FB_SLOPE_A * (dist_s - s->cu[band]);
         for (j = band + 1; j < ORC_FB_BANDS; j++) {
           d1 *= s->cu[band];
           d2 *= s->cu[band];
@@ -693,7 +711,9 @@ orc_di_basic (const double *mv)
   for (j = 0; j < 3; j++)
     x[j] = nb_wxb[j];
   for (i = 0; i < 11; i++) {
-    double m = (mv[i] - nb_amin[i]) / (nb_amax[i] - nb_amin[i]);   /* no clamping: CLAMP_MOVS 0 */
+    double m = (mv[i] - nb_amin[i]) / (nb_amax[i] - nb_amin[i]);
+    if (orc_cfg[CFG_CLAMP_MOVS])                /* nn.c:202-207 */
+      m = m < 0. ? 0. : m > 1. ? 1. : m;
     for (j = 0; j < 3; j++)
       x[j] += nb_wx[i][j] * m;
   }
@@ -711,6 +731,8 @@ orc_di_advanced (const double *mv)
     x[j] = na_wxb[j];
   for (i = 0; i < 5; i++) {
     double m = (mv[i] - na_amin[i]) / (na_amax[i] - na_amin[i]);
+    if (orc_cfg[CFG_CLAMP_MOVS])                /* nn.c:320-325 */
+      m = m < 0. ? 0. : m > 1. ? 1. : m;
     for (j = 0; j < 5; j++)
       x[j] += na_wx[i][j] * m;
   }
@@ -951,7 +973,7 @@ mov_prob_detect (orc_session *s, orc_movaccum *aadb, orc_movaccum *amfpd)
       double e = er - et;
       double bexp = er > et ? 4. : 6.;
       double pc = 1. - pow (0.5, pow (e / sd, bexp));
-      double qc = fabs (trunc (e)) / sd;        /* USE_FLOOR_FOR_STEPS_ABOVE_THRESHOLD 0 */
+      double qc = fabs (orc_cfg[CFG_FLOOR_STEPS] ? floor (e) : trunc (e)) / sd;   /* movs.c:1256-1260 */
       if (pc > p_band)
         p_band = pc;
       if (c == 0 || qc > q_band)
@@ -1000,10 +1022,16 @@ ehs_of_frame (const double *fr, const double *ft)
   }
   cavg /= LAG;
   for (i = 0; i < LAG; i++) {
-    double w = 0.81649658092773 * (1 - cos (2 * M_PI * i / (LAG - 1))) / LAG;
-    corr[i] = (corr[i] - cavg) * w;
+    /* movs.c:1362-1368 */
+    double w = orc_cfg[CFG_CENTER_EHS_WINDOW]
+      ? 0.81649658092773 * (1 + cos (2 * M_PI * i / (2 * LAG - 1))) / LAG
+      : 0.81649658092773 * (1 - cos (2 * M_PI * i / (LAG - 1))) / LAG;
+    /* movs.c:1409-1427: the mean goes before the window, or (below) as the DC bin afterwards */
+    corr[i] = orc_cfg[CFG_EHS_DC_BEFORE_WINDOW] ? (corr[i] - cavg) * w : corr[i] * w;
   }
   real_dft (corr, LAG, cr, ci);
+  if (!orc_cfg[CFG_EHS_DC_BEFORE_WINDOW])
+    cr[0] = 0.;                                 /* movs.c:1429-1433 */
   prev = cr[0] * cr[0] + ci[0] * ci[0];
   for (i = 1; i <= LAG / 2; i++) {
     double cur = cr[i] * cr[i] + ci[i] * ci[i];
@@ -1141,11 +1169,13 @@ fb_block (orc_session *s, const float *ref, const float *test)
     for (c = 0; c < s->channels; c++) {
       const double *mr = s->ref_mod[c].modulation, *mt = s->test_mod[c].modulation;
       const double *ar = s->lev[c].adapted_ref, *at = s->lev[c].adapted_test;
-      /* movs.c:551-577 with SWAP_MOD_PATTS_FOR_NOISE_LOUDNESS_MOVS 1 */
+      /* movs.c:551-577 */
       double nl = noise_loudness (b, 2.5, 0.3, 1., 0.1, mr, mt, ar, at);
-      double mc = noise_loudness (b, 1.5, 0.15, 1., 0., mt, mr, at, ar);
-      /* movs.c:679-706 (same switch): both modulation inputs are the reference's */
-      double ld = noise_loudness (b, 1.5, 0.15, 1., 0., mr, mr, ar, s->ref_fb_st[c].excitation);
+      double mc = orc_cfg[CFG_SWAP_MOD_PATTS] ? noise_loudness (b, 1.5, 0.15, 1., 0., mt, mr, at, ar)
+                                              : noise_loudness (b, 1.5, 0.15, 1., 0., mr, mt, at, ar);
+      /* movs.c:679-706 (same switch): with it both modulation inputs are the reference's */
+      double ld = noise_loudness (b, 1.5, 0.15, 1., 0., mr, orc_cfg[CFG_SWAP_MOD_PATTS] ? mr : mt, ar,
+                                  s->ref_fb_st[c].excitation);
       orc_acc_add (&s->acc[MA_NLASYM], c, nl, mc);
       orc_acc_add (&s->acc[MA_LINDIST], c, ld, 1.);
     }

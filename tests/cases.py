@@ -76,6 +76,19 @@ def level_cases():
     return cases
 
 
+def settings_cases():
+    """cases for the settings.h variants of the reference (tests/golden/ref_e2e_settings.json)"""
+    cases = []
+    for adv in (0, 1):
+        cases.append(dict(name="ats_saw_triangle", kind="ats", wave_ref="saw", wave_test="triangle", n=131072,
+                          channels=1, advanced=adv))
+        cases.append(dict(name="synth_s1_stereo", kind="synth", seed=1, channels=2, n=120000, advanced=adv))
+        cases.append(dict(name="synth_s12_mono", kind="synth", seed=12, channels=1, n=72000, advanced=adv))
+        cases.append(dict(name="synth_quiet_36dB", kind="synth", seed=28, channels=2, n=96000, atten_shift=6,
+                          advanced=adv))
+    return cases
+
+
 def stage_inputs():
     """Mono signals for the stage-level dumps (ear models)."""
     ref, test = synth_np.pair(5, 1, 8192)

@@ -90,6 +90,20 @@ class Session:
         self.close()
 
 
+SETTINGS_FIELDS = ("swap_mod_patts_for_noise_loudness_movs", "center_ehs_correlation_window",
+                   "ehs_subtract_dc_before_window", "use_floor_for_steps_above_threshold", "clamp_movs",
+                   "swap_slope_filter_coefficients")
+SETTINGS_DEFAULT = dict(zip(SETTINGS_FIELDS, (1, 0, 1, 0, 0, 0)))
+
+
+def set_settings(**changed):
+    """the reference's settings.h switches (process-wide in the oracle); no arguments = the shipped values"""
+    vals = dict(SETTINGS_DEFAULT, **changed)
+    assert set(vals) == set(SETTINGS_FIELDS), sorted(set(vals) - set(SETTINGS_FIELDS))
+    arr = (C.c_int * 6)(*[int(vals[k]) for k in SETTINGS_FIELDS])
+    lib().orc_set_settings(arr)
+
+
 def run_pair(advanced, ref, test, level=92.0):
     """ref/test: float32 [n, channels]; -> dict(movs, di, odg, totalsnr, frames)"""
     ch = ref.shape[1]

@@ -34,11 +34,11 @@ def _fix(v):
             for x in v]
 
 
-def run_harness(*args, level=None):
+def run_harness(*args, level=None, harness=HARNESS):
     env = dict(os.environ)
     if level is not None:
         env["REF_PLAYBACK_LEVEL"] = repr(float(level))
-    out = subprocess.run([str(HARNESS), *map(str, args)], check=True, capture_output=True, text=True, env=env).stdout
+    out = subprocess.run([str(harness), *map(str, args)], check=True, capture_output=True, text=True, env=env).stdout
     return json.loads(out)
 
 
@@ -100,6 +100,42 @@ def e2e_levels():
     (GOLD / "ref_e2e_level.json").write_text(json.dumps(results, indent=0))
 
 
+# the reference built with ONE settings.h switch flipped (oracle/Makefile ref_variants): name -> the
+# engine's peaq_settings field and its value in that build
+SETTINGS_VARIANTS = {
+    "swapmod0": ("swap_mod_patts_for_noise_loudness_movs", 0),
+    "center1": ("center_ehs_correlation_window", 1),
+    "dcafter": ("ehs_subtract_dc_before_window", 0),
+    "floor1": ("use_floor_for_steps_above_threshold", 1),
+    "clamp1": ("clamp_movs", 1),
+    "swapslope1": ("swap_slope_filter_coefficients", 1),
+}
+
+
+def e2e_settings():
+    """tests/golden/ref_e2e_settings.json: the other readings of BS.1387 the reference can be compiled to
+    (settings.h:47-97), each on a few end-to-end cases, basic and advanced"""
+    subprocess.run(["make", "-C", str(ROOT / "oracle"), "ref", "ref_variants"], check=True)
+    results = []
+    with tempfile.TemporaryDirectory() as td:
+        for case in case_defs.settings_cases():
+            ref, test = case_defs.make_inputs(case)
+            rp, tp = Path(td) / "r.f32", Path(td) / "t.f32"
+            ref.astype("<f4").tofile(rp)
+            test.astype("<f4").tofile(tp)
+            base = run_harness("pair", case["advanced"], case["channels"], rp, tp)
+            for variant, (field, value) in SETTINGS_VARIANTS.items():
+                r = run_harness("pair", case["advanced"], case["channels"], rp, tp,
+                                harness=ROOT / "oracle" / "_ref" / f"ref_harness_{variant}")
+                changed = [i for i, (a, b) in enumerate(zip(r["movs"], base["movs"])) if a != b]
+                results.append(dict(variant=variant, settings={field: value}, case=case, frames=r["frames"],
+                                    fb_frames=r["fb_frames"], movs=r["movs"], di=r["di"][0], odg=r["odg"][0],
+                                    movs_changed_vs_default=changed, odg_default=base["odg"][0]))
+                print(f"{variant:11s} {case['name']:24s} adv={case['advanced']} odg={r['odg'][0]} (default "
+                      f"{base['odg'][0]}) movs changed: {changed}")
+    (GOLD / "ref_e2e_settings.json").write_text(json.dumps(results, indent=0))
+
+
 def stages():
     arrays = {}
     with tempfile.TemporaryDirectory() as td:
@@ -128,6 +164,10 @@ def tables():
 
 
 def main():
+    if sys.argv[1:] == ["settings"]:                 # only the settings.h variants
+        GOLD.mkdir(parents=True, exist_ok=True)
+        e2e_settings()
+        return
     subprocess.run(["make", "-C", str(ROOT / "oracle"), "ref"], check=True)
     GOLD.mkdir(parents=True, exist_ok=True)
     # the audiotestsrc transcription must match the real element bit for bit
