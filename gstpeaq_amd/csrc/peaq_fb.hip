@@ -191,7 +191,9 @@ constexpr int kWinCols = (kWin + 31) / 32;          // 105
 // (the old stride 106 made them overlap on 12 banks: 30 % of the LDS cycles were conflicts)
 constexpr int kWinRow = 112;
 static_assert(kWinRow > kWinCols && kWinRow % 32 == 16, "window rows: long enough, and two rows apart = 32 banks");
-constexpr int kACols = 64;                          // A[band][time] row stride
+// A[band][time] row stride.  (Rows of 66 / 68 / 72 doubles take the LDS bank-conflict share of the kernel from
+// 15 % to 11 % of the active LDS cycles and change its run time by nothing measurable: 64 stays.)
+constexpr int kACols = 64;
 
 // window sample with uniform index part u (the lane adds its time point): row u mod 32,
 // column u div 32 -- lanes (time points 32 samples apart) then sit in consecutive columns

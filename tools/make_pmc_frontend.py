@@ -42,7 +42,7 @@ out = {
     "hbm_bytes_per_launch": rd + wr,
     "read_over_algorithmic": rd / algo_launch,
     "traffic_over_algorithmic": (rd + wr) / algo_launch,
-    "record_bytes_per_launch": pairs * frames * 2 * 4608 / launches,
+    "record_bytes_per_launch": pairs * frames * 2 * 2816 / launches,
     "valu_insts_per_wave": fm["SQ_INSTS_VALU"]["avg"] / w,
     "valu_fp64_insts_per_wave": fp64,
     "lds_insts_per_wave": fm["SQ_INSTS_LDS"]["avg"] / w,
@@ -51,7 +51,7 @@ out = {
     "wait_any_frac": fm["SQ_WAIT_ANY"]["avg"] / fm["SQ_WAVE_CYCLES"]["avg"],
     "note": "reads = the input samples once (50 % frame overlap and channel interleave absorbed by the per-XCD L2, "
             "plus the L2 prefetch touching every line once more from L2); writes = the per-frame records handed to the "
-            "back end (4608 B per frame and channel); no scratch traffic",
+            "back end (2816 B per frame and channel); no scratch traffic",
     "backend_kernel<109,false>": {
         "hbm_read_bytes_per_launch": be["FETCH_SIZE"]["avg"] * 1024 * 2,
         "hbm_write_bytes_per_launch": be["WRITE_SIZE"]["avg"] * 1024,
