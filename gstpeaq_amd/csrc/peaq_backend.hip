@@ -165,9 +165,11 @@ struct GlobalTabs {
   __device__ __forceinline__ double internal_noise(int b) const { return p->internal_noise[b]; }
   __device__ __forceinline__ double noise_pow03(int b) const { return p->noise_pow03[b]; }
   __device__ __forceinline__ double mask_diff(int b) const { return p->mask_diff[b]; }
+  __device__ __forceinline__ double ln_internal_noise(int b) const { return p->ln_internal_noise[b]; }
+  __device__ __forceinline__ double inv_window_count(int b) const { return p->inv_window_count[b]; }
   __device__ __forceinline__ double deriv_factor() const { return p->deriv_factor; }
 };
-enum { T_ADAPT, T_EAR, T_THR, T_LOUDF, T_EXCTHR, T_INOISE, T_NPOW03, T_MASK, T_ISN, T_ISN03, T_COUNT };
+enum { T_ADAPT, T_EAR, T_THR, T_LOUDF, T_EXCTHR, T_INOISE, T_NPOW03, T_MASK, T_ISN, T_ISN03, T_LNINOISE, T_RCNT, T_COUNT };
 struct LdsTabs {
   const double* t;                  // [T_COUNT][kBandStride] in LDS
   int off;                          // 0, but opaque to the compiler (re-read per frame, not hoisted)
@@ -181,6 +183,8 @@ struct LdsTabs {
   __device__ __forceinline__ double internal_noise(int b) const { return at(T_INOISE, b); }
   __device__ __forceinline__ double noise_pow03(int b) const { return at(T_NPOW03, b); }
   __device__ __forceinline__ double mask_diff(int b) const { return at(T_MASK, b); }
+  __device__ __forceinline__ double ln_internal_noise(int b) const { return at(T_LNINOISE, b); }
+  __device__ __forceinline__ double inv_window_count(int b) const { return at(T_RCNT, b); }
   __device__ __forceinline__ double deriv_factor() const { return deriv; }
 };
 
@@ -204,12 +208,15 @@ __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const
   }
   num = wave_sum(num);
   den = wave_sum(den);
-  const double lev = div_fast(num * num, den * den);
+  // lev = (num / den)^2 and its reciprocal, once per wave; the quotients of the per-band loop below
+  // are products with reciprocals that exist anyway (1 ulp from the reference's divisions)
+  const double n2 = num * num, d2 = den * den;
+  const double lev = div_fast(n2, d2), inv_lev = div_fast(d2, n2);
   double lc_ref[SLOTS], lc_test[SLOTS];
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     if (lev > 1) {                                           // (46)/(47)
-      lc_ref[s] = div_fast(e_ref[s], lev);
+      lc_ref[s] = e_ref[s] * inv_lev;
       lc_test[s] = e_test[s];
     } else {
       lc_ref[s] = e_ref[s];
@@ -239,8 +246,6 @@ __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const
     ad_test[s] = 0.;
     if (bl.valid(s)) {
       const int k = bl.band(s);
-      const int m1 = k < M1 ? k : M1;
-      const int m2 = (NB - k - 1) < M2 ? (NB - k - 1) : M2;
       // (50)/(51): window [k - m1, k + m2] summed in ascending order like the reference.  The
       // array is zero outside [0, NB), so the full window [k - M1, k + M2] gives the same sums
       // bit for bit (x + 0 = x) with compile-time offsets from one address.
@@ -250,9 +255,9 @@ __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const
         rr += pa_lds[kPaPad + k + j];
         rt += pa_lds[kPaStride + kPaPad + k + j];
       }
-      const double cnt = (double)(m1 + m2 + 1);
-      rr = div_fast(rr, cnt);
-      rt = div_fast(rt, cnt);
+      const double rcnt = bt.inv_window_count(k);            // 1 / (m1 + m2 + 1)
+      rr *= rcnt;
+      rt *= rcnt;
       const double a = bt.adapt_tc(k);
       st[4][s] = a * st[4][s] + (1 - a) * rr;
       st[5][s] = a * st[5][s] + (1 - a) * rt;
@@ -276,7 +281,7 @@ __device__ __forceinline__ void modulation(const BandLane<NB, SLOTS>& bl, const 
       const double dl = bt.deriv_factor() * fabs(loud[s] - st[0][s]);
       st[2][s] = a * st[2][s] + (1 - a) * dl;
       st[1][s] = a * st[1][s] + (1. - a) * loud[s];
-      mod[s] = div_fast(st[2][s], 1. + div_fast(st[1][s], 0.3));
+      mod[s] = div_fast(st[2][s], 1. + st[1][s] * (1. / 0.3));
       st[0][s] = loud[s];
     }
   }
@@ -313,7 +318,8 @@ __device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, 
       const double stest = thres_fac * mod_test[s] + s0;
       const double ethres = bt.internal_noise(bl.band(s));
       const double beta = be_exp(div_fast(-alpha * (e_test[s] - e_ref[s]), e_ref[s]));
-      nl += be_pow(div_fast(ethres, stest), 0.23) *
+      // (ethres / stest)^0.23 from the logarithms: ln ethres is a table entry
+      nl += be_exp(0.23 * (bt.ln_internal_noise(bl.band(s)) - be_log(stest))) *
             (be_pow(1. + div_fast(fmax(stest * e_test[s] - sref * e_ref[s], 0.), ethres + sref * e_ref[s] * beta), 0.23) -
              1.);
     }
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
     const BandTables* __restrict__ g = a.bands;
     const double* const src[T_COUNT] = {g->adapt_tc, g->ear_tc, g->threshold, g->loud_factor, g->exc_threshold,
                                         g->internal_noise, g->noise_pow03, g->mask_diff, g->inv_spread_norm,
-                                        g->inv_spread_norm_pow03};
+                                        g->inv_spread_norm_pow03, g->ln_internal_noise, g->inv_window_count};
 #pragma unroll
     for (int t = 0; t < T_COUNT; ++t)
       for (int i = threadIdx.x; i < kBandStride; i += blockDim.x) sh_tab[t * kBandStride + i] = src[t][i];
@@ -534,14 +540,16 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
           const double et_db = (10. * kInvLn10) * be_log(et[s]);
           const double l = 0.3 * fmax(er_db, et_db) + 0.7 * et_db;
           const double l2 = l * l;
-          const double sd = l > 0. ? 5.95072 * be_pow(div_fast(6.39468, l), 1.71332) + 9.01033e-11 * l2 * l2 +
+          // (6.39468 / l)^1.71332 = exp(1.71332 (ln 6.39468 - ln l)); one reciprocal of s for both quotients
+          const double sd = l > 0. ? 5.95072 * be_exp(1.71332 * (1.8554663946857675 - be_log(l))) + 9.01033e-11 * l2 * l2 +
                                          5.05622e-6 * l2 * l - 0.00102438 * l * l + 0.0550197 * l - 0.198719
                                    : 1e30;
+          const double inv_sd = div_fast(1., sd);
           const double e = er_db - et_db;
-          const double x = div_fast(e, sd), x2 = x * x;
+          const double x = e * inv_sd, x2 = x * x;
           const double xb = er_db > et_db ? x2 * x2 : x2 * x2 * x2;   // (e/s)^b, b = 4 or 6
           pc = 1. - be_exp(-kLn2 * xb);                             // 1 - 0.5^((e/s)^b)
-          qc = div_fast(fabs(a.cfg.floor_steps ? floor(e) : trunc(e)), sd);   // movs.c:1256-1260
+          qc = fabs(a.cfg.floor_steps ? floor(e) : trunc(e)) * inv_sd;        // movs.c:1256-1260
         }
         sh.pc[chan][bl.band(s)] = pc;
         sh.qc[chan][bl.band(s)] = qc;
@@ -580,8 +588,7 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
 #pragma unroll
       for (int s = 0; s < SLOTS; ++s) {
         if (bl.valid(s)) {
-          const double m = div_fast(er[s], bt.mask_diff(bl.band(s)));
-          const double r = div_fast(nz[s], m);
+          const double r = div_fast(nz[s] * bt.mask_diff(bl.band(s)), er[s]);   // noise / (excitation / mask)
           nsum += r;
           if (r > nmax) nmax = r;
         }

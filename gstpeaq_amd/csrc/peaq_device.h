@@ -66,6 +66,8 @@ struct BandTables {             // earmodel.c:279-323 + fftearmodel.c:693-788
   double exc_threshold[kBandStride];
   double threshold[kBandStride];
   double loud_factor[kBandStride];
+  double ln_internal_noise[kBandStride];   // ln(internal_noise): x^0.23 with that base as exp(0.23 (ln a - ln b))
+  double inv_window_count[kBandStride];    // 1 / (bands in the averaging window of leveladapter.c:315-328)
   // FFT model only
   int    lo[kBandStride], hi[kBandStride];
   double wlo[kBandStride], whi[kBandStride];

@@ -46,6 +46,13 @@ static void fill_common_bands(BandTables& t, const std::vector<double>& fc, int 
     t.fc[i] = f;
     t.internal_noise[i] = std::pow(10.0, 0.4 * 0.364 * std::pow(f / 1000.0, -0.8));
     t.noise_pow03[i] = std::pow(t.internal_noise[i], 0.3);
+    t.ln_internal_noise[i] = std::log(t.internal_noise[i]);
+    {
+      // leveladapter.c:315-328: the correction factors are averaged over [k - m1, k + m2]
+      const int M1 = t.bands / 36, M2 = t.bands / 25;
+      const int m1 = i < M1 ? i : M1, m2 = (t.bands - i - 1) < M2 ? (t.bands - i - 1) : M2;
+      t.inv_window_count[i] = 1.0 / (m1 + m2 + 1);
+    }
     t.exc_threshold[i] = std::pow(10.0, 0.364 * std::pow(f / 1000.0, -0.8));
     t.threshold[i] =
         std::pow(10.0, 0.1 * (-2.0 - 2.05 * std::atan(f / 4000.0) - 0.75 * std::atan(f / 1600.0 * f / 1600.0)));
@@ -58,6 +65,8 @@ static void fill_common_bands(BandTables& t, const std::vector<double>& fc, int 
     t.fc[i] = 1000.0;
     t.internal_noise[i] = 1.0;
     t.noise_pow03[i] = 1.0;
+    t.ln_internal_noise[i] = 0.0;
+    t.inv_window_count[i] = 1.0;
     t.exc_threshold[i] = 1.0;
     t.threshold[i] = 0.5;
     t.loud_factor[i] = 0.0;
