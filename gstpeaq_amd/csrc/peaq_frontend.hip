@@ -285,18 +285,22 @@ struct FrameSrc {
     float* p = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
     rs = __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane((int)l * channels * 4), 0x00020000);
   }
-  // samples 2 n and 2 n + 1 of this channel
-  __device__ __forceinline__ void load2(int n, float& x0, float& x1) const {
+  // byte offset of this lane's first sample pair; pair lane + 64 r sits r * row_bytes() further on
+  __device__ __forceinline__ int lane_offset(int lane) const { return channels == 1 ? lane * 8 : lane * 16 + chan * 4; }
+  // samples 2 n and 2 n + 1 of this channel, n = lane + 64 r: ONE lane offset for all r (voff = lane_offset),
+  // the row as the instruction's scalar offset -- no vector arithmetic per load; the range check covers
+  // vector + scalar + immediate offset (tools/scratch/oob_soffset.hip)
+  __device__ __forceinline__ void load2(int r, int voff, float& x0, float& x1) const {
     if (channels == 1) {
-      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, n * 8, 0, 0);
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, r * 512, 0);
       x0 = __uint_as_float(v.x);
       x1 = __uint_as_float(v.y);
     } else {
       // two 4-byte loads of this channel rather than 16 bytes of both: half the data through the
       // return path of the vector-memory pipe (its busiest part), no selects, and the sibling
       // channel's workgroup finds the lines in L2 either way (+2 % measured)
-      x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, n * 16 + chan * 4, 0, 0));
-      x1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, n * 16 + chan * 4 + 8, 0, 0));
+      x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, r * 1024, 0));
+      x1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff + 8, r * 1024, 0));
     }
   }
 };
@@ -389,11 +393,12 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
   float amax = 0.f;
   double energy = 0., hop = 0.;                      // hop: sum ref^2 (reference wave) / sum (ref - test)^2 (test wave)
   {
+    const int voff = src.lane_offset(lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = lane + 64 * r;
       float x0, x1;
-      src.load2(n, x0, x1);
+      src.load2(r, voff, x0, x1);
       const double w0 = fma(hl0.y, kHannS[r], fma(-hl0.x, kHannC[r], kHannA));
       const double w1 = fma(hl1.y, kHannS[r], fma(-hl1.x, kHannC[r], kHannA));
       z[r] = {w0 * (double)x0, w1 * (double)x1};
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
         hop += (double)(x1 * x1);
       } else {
         float r0, r1;
-        src_ref.load2(n, r0, r1);
+        src_ref.load2(r, voff, r0, r1);               // same channel count and channel: same lane offset
         hop += (double)((r0 - x0) * (r0 - x0));
         hop += (double)((r1 - x1) * (r1 - x1));
       }
@@ -457,11 +462,12 @@ __global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendAr
       float* ax = reinterpret_cast<float*>(unit);
       int lane_q = lane;                             // opaque copy: recompute the indices here rather
       asm volatile("" : "+v"(lane_q));               // than keep 16 of them alive from the first loop
+      const int voff_q = src.lane_offset(lane_q);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = lane_q + 64 * r;
         float x0, x1;
-        src.load2(n, x0, x1);
+        src.load2(r, voff_q, x0, x1);
         reinterpret_cast<float2*>(ax)[n] = make_float2(fabsf(x0), fabsf(x1));
       }
       wave_lds_fence();
