@@ -45,6 +45,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s
 FLOP_PER_FRAME_PAIR = 0.45e6          # SURVEY.md 8(d), reported alongside
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 FP32_MATRIX_PEAK_TFLOPS = 157.3        # v_mfma_f32_16x16x4_f32 (MI355X_MICROARCH.md)
+FP16_MATRIX_PEAK_TFLOPS = 2516.0       # v_mfma_f32_16x16x32_f16, dense (MI355X_MICROARCH.md: 2.5 PFLOP/s)
 CONFIG4_PAIRS_PER_GPU = 32768         # BASELINE.json configs[3]: 262 144 pairs over 8 GPUs
 WAVE_PAIRS = 4096
 
@@ -328,12 +329,15 @@ def main():
         flops = blocks * args.channels * 2 * 6 * 10914 * 6
         fb_s = timing["fb_ms"] * 1e-3
         tf = flops / fb_s / 1e12 if fb_s > 0 else 0.0
-        fp64 = ctx.fir_fp64()
-        peak = FP64_VECTOR_PEAK_TFLOPS if fp64 else FP32_MATRIX_PEAK_TFLOPS
+        mode = ctx.fir_mode()
+        peak = {"f64": FP64_VECTOR_PEAK_TFLOPS, "f32": FP32_MATRIX_PEAK_TFLOPS, "f16x3": FP16_MATRIX_PEAK_TFLOPS}[mode]
         return {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
                 "frac": tf / peak, "traffic": None,
-                "kernel": "fb_bank_kernel<MfmaF64>" if fp64 else "fb_bank_kernel<MfmaF32>",
-                "peak_is": "FP64 matrix = vector peak" if fp64 else "FP32 matrix peak (f32-input MFMA), MI355X_MICROARCH.md",
+                "kernel": {"f64": "fb_bank_kernel<MfmaF64>", "f32": "fb_bank_kernel<MfmaF32>", "f16x3": "fb_bank_kernel<MfmaH3>"}[mode],
+                "peak_is": {"f64": "FP64 matrix = vector peak", "f32": "FP32 matrix peak (f32-input MFMA), MI355X_MICROARCH.md",
+                            "f16x3": "dense FP16 matrix peak, MI355X_MICROARCH.md; the kernel issues 6x the algorithmic "
+                                     "multiply-adds (three FP16 products per term, the fold of the symmetric taps undone) "
+                                     "and spends most of its time in its FP64 vector phases, DESIGN.md 3"}[mode],
                 "launches": timing["fb_launches"], "avg_launch_ms": timing["fb_ms"] / max(timing["fb_launches"], 1),
                 "algorithmic_flop_per_launch": flops / max(timing["fb_launches"], 1),
                 "frontend_ms": timing["frontend_ms"], "backend_ms": timing["backend_ms"],
@@ -393,8 +397,10 @@ def main():
                    "value": ma["fp_all"] * adv_steps / ma["timed"], "unit": "frame-pairs/s", "steps": adv_steps,
                    "warmup": 1, "ms_per_step": ma["timed"] / adv_steps * 1e3,
                    "fb_blocks_per_frame_pair": float(ma["gathered"][:, 15].sum().item()) / max(ma["fp_all"], 1.0),
-                   "dtype": "f64, FIR bank of the filter-bank ear model on " + ("v_mfma_f64" if ctx.fir_fp64() else
-                            "v_mfma_f32 (max |dODG| 5e-8 vs all-FP64, profiles/r02_precision_ledger.json)"),
+                   "dtype": "f64, FIR bank of the filter-bank ear model on " + {
+                       "f64": "v_mfma_f64", "f32": "v_mfma_f32 (max |dODG| 5e-8 vs all-FP64, profiles/r02_precision_ledger.json)",
+                       "f16x3": "v_mfma_f32_16x16x32_f16 with both operands split into two FP16 parts, three products per term "
+                                "(max |dODG| 1e-7 vs all-FP64, profiles/r02_precision_ledger.json)"}[ctx.fir_mode()],
                    "roofline": filterbank_roofline(ma),
                    "odg_mean": float(ma["gathered"][:, 12][~torch.isnan(ma["gathered"][:, 12])].mean().item())}
         rows_adv = ma["rows"]

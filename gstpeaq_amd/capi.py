@@ -89,6 +89,8 @@ def load_library():
     L.peaq_ctx_get_settings.argtypes = [vp, C.POINTER(Settings)]
     L.peaq_ctx_set_fir_fp64.argtypes = [vp, C.c_int]
     L.peaq_ctx_get_fir_fp64.argtypes = [vp]
+    L.peaq_ctx_set_fir_mode.argtypes = [vp, C.c_int]
+    L.peaq_ctx_get_fir_mode.argtypes = [vp]
     L.peaq_session_create.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.POINTER(vp)]
     L.peaq_session_destroy.argtypes = [vp]
     L.peaq_session_push.argtypes = [vp, C.c_int, fp, C.c_size_t]
@@ -174,6 +176,13 @@ class Context:
     def set_fir_fp64(self, enable):
         """advanced version: FIR bank on the FP64 matrix instruction (default: FP32, see include/peaq_amd.h)"""
         _check(self.L.peaq_ctx_set_fir_fp64(self.h, int(bool(enable))))
+
+    def set_fir_mode(self, mode):
+        """'f32' | 'f64' | 'f16x3' (include/peaq_amd.h PEAQ_FIR_*)"""
+        _check(self.L.peaq_ctx_set_fir_mode(self.h, {"f32": 0, "f64": 1, "f16x3": 2}[mode]))
+
+    def fir_mode(self):
+        return ("f32", "f64", "f16x3")[self.L.peaq_ctx_get_fir_mode(self.h)]
 
     def fir_fp64(self):
         return bool(self.L.peaq_ctx_get_fir_fp64(self.h))

@@ -130,7 +130,7 @@ struct peaq_ctx {
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
   unsigned long long* d_prof = nullptr;   // -DPEAQ_FE_PROFILE builds only
-  int fir_fp64 = 0;                       // advanced version: FIR bank on the FP64 instead of the FP32 matrix instruction
+  int fir_fp64 = 2;                       // advanced version: arithmetic of the FIR bank (PEAQ_FIR_*; default the split-FP16 form)
   Settings settings;                      // the reference's settings.h switches (peaq_ctx_set_settings)
 
   hipEvent_t next_event() {
@@ -157,7 +157,17 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
   c->device = device;
   {
     const char* e = std::getenv("PEAQ_AMD_FIR_FP64");
-    c->fir_fp64 = e && *e && *e != '0';
+    if (e && *e && *e != '0') c->fir_fp64 = 1;
+    if (const char* m = std::getenv("PEAQ_AMD_FIR")) {     // "f16x3" | "f32" | "f64"
+      const std::string mode(m);
+      if (mode == "f64") c->fir_fp64 = 1;
+      else if (mode == "f32") c->fir_fp64 = 0;
+      else if (mode == "f16x3") c->fir_fp64 = 2;
+      else {
+        delete c;
+        return fail(PEAQ_ERR_ARG, "PEAQ_AMD_FIR: expected f16x3, f32 or f64");
+      }
+    }
   }
   if (const char* e = std::getenv("PEAQ_AMD_SETTINGS")) {
     // "CLAMP_MOVS=1,center_ehs_correlation_window=1": the settings.h macro names, any case -- lets the CLI and
@@ -272,10 +282,19 @@ extern "C" int peaq_ctx_device(const peaq_ctx* c) { return c ? c->device : -1; }
 extern "C" int peaq_ctx_set_fir_fp64(peaq_ctx* c, int enable) {
   if (!c) return fail(PEAQ_ERR_ARG, "peaq_ctx_set_fir_fp64: ctx is NULL");
   std::lock_guard<std::mutex> lock(c->mu);
-  c->fir_fp64 = enable ? 1 : 0;
+  c->fir_fp64 = enable ? 1 : 2;                      // off = back to the default (PEAQ_FIR_F16X3)
   return PEAQ_OK;
 }
-extern "C" int peaq_ctx_get_fir_fp64(const peaq_ctx* c) { return c ? c->fir_fp64 : -1; }
+extern "C" int peaq_ctx_get_fir_fp64(const peaq_ctx* c) { return c ? c->fir_fp64 == 1 : -1; }
+
+extern "C" int peaq_ctx_set_fir_mode(peaq_ctx* c, int mode) {
+  if (!c) return fail(PEAQ_ERR_ARG, "peaq_ctx_set_fir_mode: ctx is NULL");
+  if (mode < 0 || mode > 2) return fail(PEAQ_ERR_ARG, "peaq_ctx_set_fir_mode: mode must be PEAQ_FIR_F32, _F64 or _F16X3");
+  std::lock_guard<std::mutex> lock(c->mu);
+  c->fir_fp64 = mode;
+  return PEAQ_OK;
+}
+extern "C" int peaq_ctx_get_fir_mode(const peaq_ctx* c) { return c ? c->fir_fp64 : -1; }
 
 extern "C" void peaq_settings_default(peaq_settings* s) {
   if (!s) return;
@@ -379,6 +398,15 @@ extern "C" size_t peaq_batch_workspace_bytes(int advanced, int channels, int n_p
   return b;
 }
 
+// split-FP16 FIR (FbFrontArgs.fir_fp64 == 2): the power of two that puts the filtered signal's full scale --
+// |x| = 1 times the playback-level factor -- between 2^10 and 2^11 of FP16's 65504 (30 dB of headroom for
+// samples beyond full scale and for the high-pass filter's overshoot)
+static void set_fir_scale(FbFrontArgs& ff) {
+  const int e = 10 - std::ilogb(ff.level_factor);
+  ff.hf_xscale = std::ldexp(1., e);
+  ff.hf_xunscale = std::ldexp(1., -e);
+}
+
 static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n_pairs, const float* d_ref,
                                const float* d_test, size_t pair_stride, const uint32_t* d_nref,
                                const uint32_t* d_ntest, uint32_t n_uniform, const uint32_t* d_nblocks,
@@ -414,6 +442,7 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
     ff.block_origin = 0;
     ff.channels = channels;
     ff.level_factor = fb_level_factor(level_db);
+    set_fir_scale(ff);
     ff.bands = c->d_bands40;
     ff.fb = c->d_fb;
     ff.fbstate = c->fbstate.as<FbSignalState>();
@@ -780,6 +809,7 @@ extern "C" int peaq_debug_filterbank(peaq_ctx* c, int channels, double level_db,
   ff.n_blocks_uniform = n_blocks;
   ff.channels = channels;
   ff.level_factor = fb_level_factor(level_db);
+  set_fir_scale(ff);
   ff.bands = c->d_bands40;
   ff.fb = c->d_fb;
   ff.fbstate = st.as<FbSignalState>();
@@ -1064,6 +1094,7 @@ static int session_run_blocks(peaq_session* s, unsigned nb, const uint64_t n_val
   ff.prev_blocks = s->fb_prev_blocks;
   ff.first_launch = s->fb_first;
   ff.level_factor = fb_level_factor(s->level_db);
+  set_fir_scale(ff);
   ff.bands = c->d_bands40;
   ff.fb = c->d_fb;
   ff.fbstate = s->fbstate.as<FbSignalState>();
@@ -1564,6 +1595,7 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
     ff.channels = b->channels;
     ff.blocks_per_launch = max_nb;
     ff.level_factor = fb_level_factor(b->level_db);
+    set_fir_scale(ff);
     ff.bands = c->d_bands40;
     ff.fb = c->d_fb;
     ff.fbstate = b->fbstate.as<FbSignalState>();

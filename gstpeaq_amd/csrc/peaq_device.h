@@ -30,6 +30,19 @@ constexpr int kMfD0[kMfTiles]    = {2, 470, 677};
 constexpr int kMfSteps[kMfTiles] = {182, 65, 14};
 constexpr int kMfBase[kMfTiles]  = {0, 182, 247};
 constexpr int kMfTotalSteps = 261;
+// The same bank on the FP16 matrix instruction (v_mfma_f32_16x16x32_f16: 32 delays per instruction at
+// 15 x the MAC rate of the FP32 one) with both operands split into a high and a low FP16 part, three
+// products per term (hi hi, hi lo, lo hi: 22 bits), and the fold undone -- re = Hre X1 + Hre X2,
+// im = Him X1 - Him X2 with X1[d][t] = x[32 t - d], X2[d][t] = x[32 t - (1458 - d)] -- so that the B
+// operands are plain 16-byte reads of the window.  A row tile's delays are cut into blocks of 32 that start
+// at kHfD1 (X1, = 1 mod 8) and kHfD2 (X2, = 2 mod 8): that puts both operands' 8-sample groups on 16-byte
+// boundaries of the window; delays outside a band's filter carry zero coefficients.
+constexpr int kHfBlocks[kMfTiles] = {23, 9, 2};
+constexpr int kHfBase[kMfTiles]   = {0, 23, 32};
+constexpr int kHfD1[kMfTiles]     = {1, 465, 673};
+constexpr int kHfD2[kMfTiles]     = {2, 466, 674};
+constexpr int kHfTotalBlocks = 34;
+enum { HF_RE_HI_1, HF_RE_LO_1, HF_IM_HI_1, HF_IM_LO_1, HF_RE_HI_2, HF_RE_LO_2, HF_NIM_HI_2, HF_NIM_LO_2, HF_OPERANDS };
 
 // ---- constant tables (built on the host in FP64, peaq_tables.cpp) ----------
 struct CommonTables {
@@ -91,6 +104,11 @@ struct FbTables {               // fbearmodel.c:57-61,182-225
   double mf_im[kMfTotalSteps * 64];
   float  mf_re_f[kMfTotalSteps * 64];   // the same, rounded, for the FP32 matrix instruction
   float  mf_im_f[kMfTotalSteps * 64];
+  // FP16 x 3 form: A operands [block][operand][lane][8] as raw FP16 bits -- lane = band_in_tile + 16 kg holds the
+  // delays kHfD1 + 32 s + 8 kg + (7 - e) (X1: the window is read in ascending sample order) or
+  // kHfD2 + 32 s + 8 kg + e (X2), e = 0..7, scaled by 2^hf_exp[band] -- and the factor that undoes that scale
+  unsigned short hf[kHfTotalBlocks][HF_OPERANDS][64][8];
+  double hf_unscale[kMfTiles * 16];     // 2^-hf_exp per band row (0 for the rows beyond band 39)
 };
 
 // ---- per-frame record: front end -> back end --------------------------------

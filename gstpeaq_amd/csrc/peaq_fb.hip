@@ -199,11 +199,56 @@ constexpr int kACols = 64;
 // column u div 32 -- lanes (time points 32 samples apart) then sit in consecutive columns
 __host__ __device__ constexpr int win_off(int u) { return (u & 31) * kWinRow + (u >> 5); }
 
-// WT = the type the FIR phase computes in: double (v_mfma_f64_16x16x4_f64) or float
-// (v_mfma_f32_16x16x4_f32, twice the rate; see fir_mfma).  Everything after the FIR is FP64 either way.
+// The window of the filtered signal in LDS, B operand of the GEMM.  WT = the type the FIR phase computes in:
+// double (v_mfma_f64_16x16x4_f64), float (v_mfma_f32_16x16x4_f32) -- 32 rows of kWinRow, see win_off -- or
+// _Float16 (v_mfma_f32_16x16x32_f16 on split operands, fir_mfma_h3): two linear arrays (high and low part) with
+// 16 bytes of padding after every 32 samples, so that the sixteen time points of a B operand (32 samples = 80
+// bytes apart) start on sixteen different groups of four banks.
+template <typename WT>
+struct Window {
+  WT v[32 * kWinRow];
+  __device__ __forceinline__ void put(int u, double x, double /*scale*/) { v[win_off(u)] = (WT)x; }
+  __device__ __forceinline__ double get(int u, double /*unscale*/) const { return (double)v[win_off(u)]; }
+  // the next tile's window starts 60 columns (1920 samples) further on
+  __device__ __forceinline__ void shift(int tid) {
+    for (int e = tid; e < 32 * (kWinCols - kTileSub); e += 256) {
+      const int r = e / (kWinCols - kTileSub), c = e - r * (kWinCols - kTileSub);
+      v[r * kWinRow + c] = v[r * kWinRow + kTileSub + c];
+    }
+  }
+};
+constexpr int kWinHBlocks = 109;                    // blocks of 32 samples: window index up to 1455 + 32 * 63 + 7
+constexpr int kWinHBytes = kWinHBlocks * 80;
+__host__ __device__ constexpr int winh_off(int u) { return 2 * u + 16 * (u >> 5); }   // byte offset of sample u
+template <>
+struct Window<_Float16> {
+  alignas(16) unsigned char hi[kWinHBytes];
+  alignas(16) unsigned char lo[kWinHBytes];
+  __device__ __forceinline__ void put(int u, double x, double scale) {
+    // (full scale sits at 2^10..2^11: a sample 30 dB beyond it would leave FP16's range -- saturate rather than
+    // let an infinity turn the whole tile into NaN)
+    const float s = fminf(fmaxf((float)(x * scale), -65504.f), 65504.f);
+    const _Float16 h = (_Float16)s;
+    *reinterpret_cast<_Float16*>(hi + winh_off(u)) = h;
+    *reinterpret_cast<_Float16*>(lo + winh_off(u)) = (_Float16)(s - (float)h);
+  }
+  __device__ __forceinline__ double get(int u, double unscale) const {
+    return ((double)*reinterpret_cast<const _Float16*>(hi + winh_off(u)) +
+            (double)*reinterpret_cast<const _Float16*>(lo + winh_off(u))) * unscale;
+  }
+  __device__ __forceinline__ void shift(int tid) {   // 60 blocks = 4800 bytes; source and destination do not overlap
+    constexpr int kMove = (kWinHBytes - kTileSub * 80) / 16;
+    static_assert(kMove <= 256 && kWinHBytes - kTileSub * 80 <= kTileSub * 80, "one 16-byte piece per thread, no overlap");
+    if (tid < kMove) {
+      reinterpret_cast<uint4*>(hi)[tid] = reinterpret_cast<const uint4*>(hi + kTileSub * 80)[tid];
+      reinterpret_cast<uint4*>(lo)[tid] = reinterpret_cast<const uint4*>(lo + kTileSub * 80)[tid];
+    }
+  }
+};
+
 template <typename WT>
 struct BankLds {
-  WT win[32 * kWinRow];                             // phase 1: the filtered signal, B operand of the GEMM
+  Window<WT> win;                                   // phase 1: the filtered signal
   struct {
     double re[kFbBands][kACols];                    // A[band][time]: GEMM result, then phases 2..4 in place
     double im[kFbBands][kACols];
@@ -252,6 +297,13 @@ struct MfmaF32 {
   typedef float T;
   typedef v4f Acc;
   static __device__ __forceinline__ Acc mma(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int kk, int i) { return 4 * kk + i; }
+};
+
+// split-FP16 variant (fir_mfma_h3): accumulators and result layout of the FP32 instruction
+struct MfmaH3 {
+  typedef _Float16 T;
+  typedef v4f Acc;
   static __device__ __forceinline__ int row(int kk, int i) { return 4 * kk + i; }
 };
 
@@ -318,8 +370,8 @@ __device__ __forceinline__ void fir_mfma(BankLds<typename M::T>& sh, const typen
     // window has 1456 + 59 * 32 samples, the delays stay below 736)
     T bx[4], by[4];
     auto fetch = [&](T (&x)[4], T (&y)[4]) {
-      const T* p1 = sh.win + win_off(u1) + j;        // time points j, 16 + j, 32 + j, 48 + j
-      const T* p2 = sh.win + win_off(u2) + j;
+      const T* p1 = sh.win.v + win_off(u1) + j;        // time points j, 16 + j, 32 + j, 48 + j
+      const T* p2 = sh.win.v + win_off(u2) + j;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         x[q] = lds_rd(p1 + 16 * q);
@@ -416,8 +468,8 @@ __device__ __forceinline__ void fir_mfma_f32(BankLds<float>& sh, const float* __
     }
     v2f xa, xb, ya, yb;                              // the operands of the step about to run
     auto fetch = [&](int k) {
-      const float* p1 = sh.win + o1[k];
-      const float* p2 = sh.win + o2[k];
+      const float* p1 = sh.win.v + o1[k];
+      const float* p2 = sh.win.v + o2[k];
       xa = v2f{p1[0], p1[16]};
       xb = v2f{p1[32], p1[48]};
       ya = v2f{p2[0], p2[16]};
@@ -460,6 +512,84 @@ __device__ __forceinline__ void fir_mfma_f32(BankLds<float>& sh, const float* __
     }
     const Acc accr[4] = {ar0, ar1, ar2, ar3}, acci[4] = {ai0, ai1, ai2, ai3};
     fir_store<M>(sh, sg.r, j, kk, accr, acci);
+    g += n;
+  }
+}
+
+// The bank on v_mfma_f32_16x16x32_f16 (peaq_device.h kHf*): per block of 32 delays and time tile twelve
+// instructions -- {re, im} x {X1, X2} x {hi hi, hi lo, lo hi} -- at 17 cycles each against eight FP32 ones at 32
+// for FOUR delays, and no vector arithmetic on the operands at all: a B operand is one 16-byte LDS read of
+// the split window (lane = time point + 16 x delay group: eight consecutive samples), an A operand one
+// 16-byte read of the coefficient table through L2, reused for the four time tiles.  The 34 blocks are cut
+// into four runs (9 + 9 + 8 + 8), one per wave; a run's tiles are scaled back (power-of-two factors of
+// signal and band) and added into A with LDS atomics like the FP32 form's.
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void fir_mfma_h3(BankLds<_Float16>& sh, const FbTables* __restrict__ fb, double xunscale, int wv,
+                                            int lane) {
+  typedef v4f Acc;
+  const int j = lane & 15, kg = lane >> 4;
+  int g = wv < 2 ? 9 * wv : 18 + 8 * (wv - 2);
+  const int g_end = g + (wv < 2 ? 9 : 8);
+  static_assert(9 + 9 + 8 + 8 == kHfTotalBlocks, "split of the blocks over the four waves");
+  typedef const __attribute__((address_space(3))) v8h* lds_v8h;
+  const lds_v8h whi = (lds_v8h)sh.win.hi, wlo = (lds_v8h)sh.win.lo;
+  while (g < g_end) {
+    const int r = g >= kHfBase[2] ? 2 : g >= kHfBase[1] ? 1 : 0;
+    const int base = r == 2 ? kHfBase[2] : r == 1 ? kHfBase[1] : 0;
+    const int blocks = r == 2 ? kHfBlocks[2] : r == 1 ? kHfBlocks[1] : kHfBlocks[0];
+    const int d1 = r == 2 ? kHfD1[2] : r == 1 ? kHfD1[1] : kHfD1[0];
+    const int d2 = r == 2 ? kHfD2[2] : r == 1 ? kHfD2[1] : kHfD2[0];
+    const int s0 = g - base;
+    const int n = min(blocks - s0, g_end - g);
+    const Acc zero = {0, 0, 0, 0};
+    Acc ar[4] = {zero, zero, zero, zero}, ai[4] = {zero, zero, zero, zero};
+    // window positions of this lane's eight samples at time tile 0 (16-byte units: the arrays are read as v8h);
+    // a block further on X1 moves one 80-byte block down, X2 one up; a time tile is 16 blocks (1280 bytes) up
+    int p1 = winh_off(kFbRing - (d1 + 32 * s0 + 8 * kg + 7) + 32 * j) / 16;
+    int p2 = winh_off(d2 + 32 * s0 + 8 * kg - 2 + 32 * j) / 16;
+    // (Requesting the coefficients a block ahead and the window operands a time tile ahead was measured: 5.40
+    // against 5.76 M frame-pairs/s -- the second wave of the SIMD already covers those latencies, the extra
+    // live registers only cost.)
+    const v8h* __restrict__ tab = reinterpret_cast<const v8h*>(&fb->hf[g][0][lane][0]);   // [block][operand][lane]
+    for (int s = 0; s < n; ++s) {
+      v8h h[HF_OPERANDS];
+#pragma unroll
+      for (int o = 0; o < HF_OPERANDS; ++o) h[o] = tab[(s * HF_OPERANDS + o) * 64];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const v8h x1h = whi[p1 + 80 * nt], x1l = wlo[p1 + 80 * nt], x2h = whi[p2 + 80 * nt], x2l = wlo[p2 + 80 * nt];
+        Acc cr = ar[nt], ci = ai[nt];
+        cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[HF_RE_HI_1], x1h, cr, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[HF_IM_HI_1], x1h, ci, 0, 0, 0);
+        cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[HF_RE_HI_2], x2h, cr, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[HF_NIM_HI_2], x2h, ci, 0, 0, 0);
+        cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[HF_RE_HI_1], x1l, cr, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[HF_IM_HI_1], x1l, ci, 0, 0, 0);
+        cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[HF_RE_HI_2], x2l, cr, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[HF_NIM_HI_2], x2l, ci, 0, 0, 0);
+        cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[HF_RE_LO_1], x1h, cr, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[HF_IM_LO_1], x1h, ci, 0, 0, 0);
+        cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[HF_RE_LO_2], x2h, cr, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[HF_NIM_LO_2], x2h, ci, 0, 0, 0);
+        ar[nt] = cr;
+        ai[nt] = ci;
+      }
+      p1 -= 5;                                       // 80 bytes
+      p2 += 5;
+    }
+    // D layout: column = lane & 15 (time), row = 4 (lane >> 4) + i  ->  band 16 r + row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = 16 * r + 4 * kg + i;
+      if (b < kFbBands) {
+        const double us = fb->hf_unscale[b] * xunscale;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          atomicAdd(&sh.a.re[b][16 * nt + j], (double)ar[nt][i] * us);
+          atomicAdd(&sh.a.im[b][16 * nt + j], (double)ai[nt][i] * us);
+        }
+      }
+    }
     g += n;
   }
 }
@@ -599,13 +729,15 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
     // predecessor (moved inside LDS) and take the 1920 new ones from registers, where they were
     // requested a whole tile ago (see below phase 2a) -------------------------------------------------
     if (b0 == 0) {
+      if constexpr (sizeof(WT) == 2)                 // beyond the window proper: read by the unused time points 60..63 only
+        for (int wdx = kWin + tid; wdx < 32 * kWinHBlocks; wdx += 256) sh.win.put(wdx, 0., 0.);
       const int avail = (int)min((size_t)kWin, row_valid);
-      for (int wdx = tid; wdx < kWin; wdx += 256) sh.win[win_off(wdx)] = wdx < avail ? (WT)row[wdx] : (WT)0;
+      for (int wdx = tid; wdx < kWin; wdx += 256) sh.win.put(wdx, wdx < avail ? row[wdx] : 0., a.hf_xscale);
     } else {
 #pragma unroll
       for (int q = 0; q < kPre; ++q) {
         const int wdx = kKeep + tid + 256 * q;
-        if (wdx < kWin) sh.win[win_off(wdx)] = (WT)pre[q];
+        if (wdx < kWin) sh.win.put(wdx, pre[q], a.hf_xscale);
       }
     }
     {
@@ -615,10 +747,12 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
     __syncthreads();
     FB_MARK(0);
     // ---- phase 1: the complex FIR filters (fbearmodel.c:399-435) as a GEMM on the matrix cores ---
-    if (sizeof(WT) == 8)
+    if constexpr (sizeof(WT) == 8)
       fir_mfma<M>(sh, reinterpret_cast<const WT*>(fb->mf_re), reinterpret_cast<const WT*>(fb->mf_im), wv, lane);
+    else if constexpr (sizeof(WT) == 4)
+      fir_mfma_f32(sh, fb->mf_re_f, fb->mf_im_f, wv, lane);
     else
-      fir_mfma_f32(reinterpret_cast<BankLds<float>&>(sh), fb->mf_re_f, fb->mf_im_f, wv, lane);
+      fir_mfma_h3(sh, fb, a.hf_xunscale, wv, lane);
     FB_MARK(1);
     __syncthreads();                                                 // A is complete
     FB_MARK(2);
@@ -634,7 +768,7 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       // band 0 (= re[0] of wave 0): its tap at delay 1456 reads the NEWEST sample in the reference
       // (the doubled ring buffer makes fb_buf[offset + 1456] alias fb_buf[offset], fbearmodel.c:413-414)
       const int tt = lane < kTileSub ? lane : kTileSub - 1;
-      const double delta = (double)sh.win[win_off(kFbRing) + tt] - (double)sh.win[win_off(0) + tt];
+      const double delta = sh.win.get(kFbRing + 32 * tt, a.hf_xunscale) - sh.win.get(32 * tt, a.hf_xunscale);
       re[0] = fma(fb->h_re[1], delta, re[0]);
       im[0] = fma(-fb->h_im[1], delta, im[0]);
       sh.a.re[0][lane] = re[0];                      // band 0 is nobody's spreading target
@@ -646,10 +780,7 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
     // the next tile's first 45 (a tile advances by 60 columns = 1920 samples); the new samples are
     // requested now and land in registers while phases 2b..5 run ---------------------------------------
     if (b0 + kTileBlocks < nb_mine) {
-      for (int e = tid; e < 32 * (kWinCols - kTileSub); e += 256) {
-        const int r = e / (kWinCols - kTileSub), c = e - r * (kWinCols - kTileSub);
-        sh.win[r * kWinRow + c] = sh.win[r * kWinRow + kTileSub + c];
-      }
+      sh.win.shift(tid);
       const size_t first = (size_t)(b0 + kTileBlocks) * kFbFrame;    // row index of the next window's u = 0
       const double* src = row + first;
       const int avail = (int)min((size_t)kWin, row_valid - first);
@@ -785,8 +916,10 @@ hipError_t launch_fb_hp(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stre
 hipError_t launch_fb_bank(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream) {
   const unsigned n_signals = n_pairs * a.channels * 2;
   if (n_signals == 0 || a.blocks_per_launch == 0) return hipSuccess;
-  if (a.fir_fp64)
+  if (a.fir_fp64 == 1)
     hipLaunchKernelGGL(fb_bank_kernel<MfmaF64>, dim3(n_signals), dim3(256), 0, stream, a, n_signals);
+  else if (a.fir_fp64 == 2)
+    hipLaunchKernelGGL(fb_bank_kernel<MfmaH3>, dim3(n_signals), dim3(256), 0, stream, a, n_signals);
   else
     hipLaunchKernelGGL(fb_bank_kernel<MfmaF32>, dim3(n_signals), dim3(256), 0, stream, a, n_signals);
   return hipGetLastError();

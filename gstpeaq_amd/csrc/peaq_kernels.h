@@ -105,7 +105,9 @@ struct FbFrontArgs {
   double* records;              // [pair][block - block0][channel][kFbRecDoubles]
   const FbPairWindow* windows;  // broker launches (see above); nullptr: the uniform fields apply, slot = pair
   Settings cfg;                 // swap_slope
-  int fir_fp64;                 // 1: FIR bank on v_mfma_f64 (exact to the oracle's 1e-9); 0: v_mfma_f32 (default, see peaq_fb.hip)
+  int fir_fp64;                 // arithmetic of the FIR bank (peaq_fb.hip): 0 = v_mfma_f32, 1 = v_mfma_f64 (exact to the oracle's
+                                // 1e-9), 2 = v_mfma_f32_16x16x32_f16 on operands split in two FP16 parts (three products per term)
+  double hf_xscale, hf_xunscale;   // mode 2: power of two that puts the filtered signal's full scale at 2^10..2^11, and its inverse
 };
 hipError_t launch_fb_frontend(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream);   // high-pass + filter bank
 hipError_t launch_fb_hp(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream);

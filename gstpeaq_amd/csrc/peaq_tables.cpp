@@ -204,6 +204,59 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
         fb.mf_im_f[(size_t)(kMfBase[r] + s) * 64 + lane] = (float)vi;
       }
   }
+  // the FP16 x 3 form of the same coefficients (peaq_device.h kHf*)
+  {
+    auto coef = [&](int b, int d, double& vr, double& vi) {          // as above: band b, delay d
+      vr = vi = 0.;
+      if (b >= kFbBands) return;
+      const int half = kLen[b] / 2, n = d - fb.delay[b];
+      if (n >= 1 && n <= half) {
+        vr = fb.h_re[fb.coef_off[b] + n] * (n == half ? 0.5 : 1.);
+        vi = n == half ? 0. : fb.h_im[fb.coef_off[b] + n];
+      }
+    };
+    auto bits = [](_Float16 h) {
+      unsigned short u;
+      std::memcpy(&u, &h, sizeof u);
+      return u;
+    };
+    for (int r = 0; r < kMfTiles; ++r) {
+      if (kHfD1[r] > kMfD0[r] || kHfD1[r] + 32 * kHfBlocks[r] <= kFbCentre || kHfD1[r] % 8 != 1 || kHfD2[r] % 8 != 2 ||
+          kHfD2[r] > kMfD0[r] || kHfD2[r] + 32 * kHfBlocks[r] <= kFbCentre)
+        std::abort();                                                // the blocks must cover the tile's delays
+      for (int i = 0; i < 16; ++i) {
+        const int b = 16 * r + i;
+        double peak = 0.;
+        for (int d = 1; d <= kFbCentre; ++d) {
+          double vr, vi;
+          coef(b, d, vr, vi);
+          peak = std::max(peak, std::max(std::fabs(vr), std::fabs(vi)));
+        }
+        // largest coefficient of the band in [1024, 2048): far from FP16's 65504, 25 octaves above its smallest normal
+        const int e = peak > 0. ? 10 - std::ilogb(peak) : 0;
+        fb.hf_unscale[b] = peak > 0. ? std::ldexp(1., -e) : 0.;
+        for (int s = 0; s < kHfBlocks[r]; ++s)
+          for (int kg = 0; kg < 4; ++kg)
+            for (int el = 0; el < 8; ++el) {
+              const int lane = i + 16 * kg;
+              auto& blk = fb.hf[kHfBase[r] + s];
+              for (int which = 0; which < 2; ++which) {
+                const int d = which == 0 ? kHfD1[r] + 32 * s + 8 * kg + (7 - el) : kHfD2[r] + 32 * s + 8 * kg + el;
+                double vr, vi;
+                coef(b, d, vr, vi);
+                if (which == 1) vi = -vi;                            // im = Him X1 - Him X2
+                const double sr = std::ldexp(vr, e), si = std::ldexp(vi, e);
+                const _Float16 rh = (_Float16)sr, ih = (_Float16)si;
+                const _Float16 rl = (_Float16)(sr - (double)rh), il = (_Float16)(si - (double)ih);
+                blk[which == 0 ? HF_RE_HI_1 : HF_RE_HI_2][lane][el] = bits(rh);
+                blk[which == 0 ? HF_RE_LO_1 : HF_RE_LO_2][lane][el] = bits(rl);
+                blk[which == 0 ? HF_IM_HI_1 : HF_NIM_HI_2][lane][el] = bits(ih);
+                blk[which == 0 ? HF_IM_LO_1 : HF_NIM_LO_2][lane][el] = bits(il);
+              }
+            }
+      }
+    }
+  }
   for (int k = 0; k < 6; ++k) {
     const double c = std::cos(kPi * (k - 5.0) / 12.0);
     fb.back_mask[k] = c * c * 0.9761 / 6.0;

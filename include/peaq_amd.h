@@ -97,6 +97,12 @@ int peaq_ctx_get_settings (const peaq_ctx *ctx, peaq_settings *s);
  * launches that follow. */
 int peaq_ctx_set_fir_fp64 (peaq_ctx *ctx, int enable);
 int peaq_ctx_get_fir_fp64 (const peaq_ctx *ctx);
+/* The three arithmetics of that FIR bank (same entry points otherwise): */
+#define PEAQ_FIR_F32   0   /* v_mfma_f32_16x16x4_f32 */
+#define PEAQ_FIR_F64   1   /* v_mfma_f64_16x16x4_f64: what peaq_ctx_set_fir_fp64(ctx, 1) selects */
+#define PEAQ_FIR_F16X3 2   /* v_mfma_f32_16x16x32_f16 on operands split into two FP16 parts, three products per term */
+int peaq_ctx_set_fir_mode (peaq_ctx *ctx, int mode);
+int peaq_ctx_get_fir_mode (const peaq_ctx *ctx);
 
 /* ---- session API ------------------------------------------------------------
  * Replaces, per element instance: g_object_new(PEAQ_TYPE_FFTEARMODEL /

@@ -11,9 +11,9 @@ _CTX = None
 
 def ctx():
     """The shared context of the parity tests.  It runs the filter bank's FIR on the FP64 matrix
-    instruction: that is the path held to the oracle's 1e-9 / 1e-7; the engine's default (FP32 FIR,
+    instruction: that is the path held to the oracle's 1e-9 / 1e-7; the engine's default (split-FP16 FIR,
     include/peaq_amd.h peaq_ctx_set_fir_fp64) has its own tests with its own stated tolerances
-    (tests/test_gpu_fir_fp32.py) and is what the CLI / element / feeder subprocess tests run."""
+    (tests/test_gpu_fir_modes.py) and is what the CLI / element / feeder subprocess tests run."""
     global _CTX
     if _CTX is None:
         import gstpeaq_amd

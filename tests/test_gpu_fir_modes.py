@@ -1,8 +1,9 @@
-"""The engine's DEFAULT arithmetic for the advanced version: the 40 complex FIR filters of the
-filter-bank ear model (fbearmodel.c:399-435) on the FP32 matrix instruction, everything else FP64
-(include/peaq_amd.h, peaq_ctx_set_fir_fp64; priced in profiles/r02_precision_ledger.json).
-Tolerances of THIS path, stated here and nowhere looser:
-  * per-block excitation patterns vs the oracle: 1e-4 relative (FP32 products and sums over up to
+"""The engine's reduced-precision arithmetics for the advanced version: the 40 complex FIR filters of the
+filter-bank ear model (fbearmodel.c:399-435) on the FP16 matrix instruction with split operands (the
+DEFAULT, PEAQ_FIR_F16X3) and on the FP32 matrix instruction (PEAQ_FIR_F32), everything else FP64
+(include/peaq_amd.h, peaq_ctx_set_fir_mode; priced in profiles/r02_precision_ledger.json).
+Tolerances of THESE paths, stated here and nowhere looser:
+  * per-block excitation patterns vs the oracle: 1e-4 relative (22..24-bit products and FP32 sums over up to
     1456 taps; measured: 2e-5 on noise-like signals, 5e-5 in the bands between the harmonics of a
     sawtooth, where a band's own output is what leaks from its strong neighbours; the FP64 path is
     held to 1e-9 in test_gpu_parity.py),
@@ -21,14 +22,15 @@ import oracle_lib as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def fp32_ctx():
+@pytest.fixture(params=["f16x3", "f32"])
+def fp32_ctx(request):
     import torch
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU (there is no CPU fallback in the product)")
     import gstpeaq_amd
     c = gstpeaq_amd.Context(0)
-    assert c.fir_fp64() is False, "the FP32 FIR must be the default"
+    assert c.fir_mode() == "f16x3" and c.fir_fp64() is False, "the split-FP16 FIR must be the default"
+    c.set_fir_mode(request.param)
     yield c
     c.close()
 
@@ -76,7 +78,7 @@ def test_advanced_goldens_fp32_fir(fp32_ctx, golden_dir):
         if not np.isnan(float(rec["odg"])):
             assert abs(got["odg"] - float(rec["odg"])) <= 1e-6 and abs(got["di"] - float(rec["di"])) <= 1e-6, case["name"]
             worst = max(worst, abs(got["odg"] - float(rec["odg"])))
-    print(f"FP32 FIR: max |dODG| vs the reference over {len(recs)} advanced cases: {worst:.3e}")
+    print(f"{fp32_ctx.fir_mode()} FIR: max |dODG| vs the reference over {len(recs)} advanced cases: {worst:.3e}")
 
 
 def test_fullsize_pairs_fp32_vs_fp64_fir(fp32_ctx):
@@ -90,4 +92,4 @@ def test_fullsize_pairs_fp32_vs_fp64_fir(fp32_ctx):
     assert d <= 1e-6, d
     for x, y in zip(a, b):
         np.testing.assert_allclose(x["movs"], y["movs"], rtol=2e-6, atol=1e-9)
-    print(f"FP32 vs FP64 FIR on 32 ten-second pairs: max |dODG| {d:.3e}")
+    print(f"{fp32_ctx.fir_mode()} vs FP64 FIR on 32 ten-second pairs: max |dODG| {d:.3e}")

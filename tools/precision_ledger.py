@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Mixed-precision ledger: what does FP32 cost in ODG, part by part?
 
-The baseline is the engine with everything in FP64 (PEAQ_AMD_FIR_FP64=1).  Compared with it:
-  * the engine's default, in which the filter bank's FIR filters run on the FP32 matrix instruction
-    (peaq_fb.hip, fir_mfma<MfmaF32>) -- this table is the evidence behind that default;
+The baseline is the engine with everything in FP64 (PEAQ_AMD_FIR=f64).  Compared with it:
+  * the engine's default, in which the filter bank's FIR filters run on the FP16 matrix instruction with both
+    operands split into two FP16 parts and three products per term (peaq_fb.hip, fir_mfma_h3) -- this table
+    is the evidence behind that default -- and the FP32 matrix instruction (fir_mfma_f32, PEAQ_AMD_FIR=f32);
   * an experimental build with the back end's loudness / detection pow, log, exp in FP32 (report only):
       make -C gstpeaq_amd/csrc VARIANT=fp32be EXTRA=-DPEAQ_LEDGER_FP32_BACKEND
 Every end-to-end golden case of tests/golden/ref_e2e*.json (62 cases, basic and advanced) and 8 full-size
@@ -64,9 +65,10 @@ def main():
     if args and args[0] == "--out":
         out_path = Path(args[1])
         args = args[2:]
-    libs = {"all FP64 (baseline)": ("", {"PEAQ_AMD_FIR_FP64": "1"}),
-            "engine default: FIR bank on v_mfma_f32_16x16x4_f32": ("", {}),
-            "all FP64 again (run-to-run variation)": ("", {"PEAQ_AMD_FIR_FP64": "1"})}
+    libs = {"all FP64 (baseline)": ("", {"PEAQ_AMD_FIR": "f64"}),
+            "engine default: FIR bank on v_mfma_f32_16x16x32_f16, operands split in two FP16 parts, 3 products per term": ("", {}),
+            "FIR bank on v_mfma_f32_16x16x4_f32": ("", {"PEAQ_AMD_FIR": "f32"}),
+            "all FP64 again (run-to-run variation)": ("", {"PEAQ_AMD_FIR": "f64"})}
     for a in args:
         name, spec = a.split("=", 1)
         parts = spec.split(",")
@@ -76,6 +78,7 @@ def main():
         env = dict(os.environ)
         env.pop("PEAQ_AMD_LIB", None)
         env.pop("PEAQ_AMD_FIR_FP64", None)
+        env.pop("PEAQ_AMD_FIR", None)
         env.update(extra_env)
         if path:
             env["PEAQ_AMD_LIB"] = path

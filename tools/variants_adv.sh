@@ -4,8 +4,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
 for v in "$@"; do
   if [ "$v" = main ]; then unset PEAQ_AMD_LIB; else export PEAQ_AMD_LIB=$R/gstpeaq_amd/libpeaq_amd_$v.so; fi
   echo "=== $v"
-  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fir_fp32.py -x -q 2>&1 | tail -3
-  timeout 300 python bench.py --advanced --steps 3 --warmup 1 --no-cpu-baseline > $O/vara_$v.json 2> $O/vara_$v.err
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fir_modes.py -x -q 2>&1 | tail -3
+  timeout 300 python bench.py ${VARIANT_ADV_ARGS:-} --advanced --steps 3 --warmup 1 --no-cpu-baseline > $O/vara_$v.json 2> $O/vara_$v.err
   python - <<PY
 import json
 try:
