@@ -644,8 +644,39 @@ __device__ unsigned long long g_fb_prof[4 * 16 + 4];
 #define FB_MARK(i) do { } while (0)
 #endif
 
+// The same in packed FP32 for the reduced-precision engine (split-FP16 FIR): (re, im) of a source travel as one
+// register pair, a step is one v_pk_mul_f32 and one v_pk_add_f32 at two cycles each instead of four FP64
+// instructions at four; the per-wave sums leave as FP64 atomics (ds_add_f32 is 22 x slower, see BankLds).
+template <int W, typename WT>
+__device__ __forceinline__ void spread_up_f32(BankLds<WT>& sh, const double (&re)[10], const double (&im)[10],
+                                              const double (&cu)[10], int lane) {
+  v2f t[10], c[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    t[i] = v2f{(float)re[i], (float)im[i]};
+    c[i] = v2f{(float)cu[i], (float)cu[i]};
+  }
+#pragma unroll
+  for (int j = 1; j < kFbBands; ++j) {
+    v2f sum = {0.f, 0.f};
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      if (wave_band(W, i) < j) {                     // compile time
+        t[i] *= c[i];
+        sum += t[i];
+        any = true;
+      }
+    }
+    if (any) {
+      atomicAdd(&sh.a.re[j][lane], (double)sum.x);
+      atomicAdd(&sh.a.im[j][lane], (double)sum.y);
+    }
+  }
+}
+
 template <typename M>
-__global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned n_signals) {
+__device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_signals) {
   typedef typename M::T WT;
   __shared__ BankLds<WT> sh;
   const int tid = threadIdx.x;
@@ -803,19 +834,42 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
       const int b = wave_band(wv, i);
       // pow(DIST, s), s = max(4, 24 + 230/fc - 0.2 L), L = 10 log10 |A|^2 (fbearmodel.c:329-333), as
       // exp(min(4 ln DIST, ln DIST (24 + 230/fc) - 2 ln DIST / ln 10 * ln |A|^2))  (ln DIST < 0)
-      const double dist_s = exp_fast(fmin(4. * kLnDist, c0[i] + kC1 * log_nonneg(re[i] * re[i] + im[i] * im[i])));
-      const double v = wave_prefix_geometric(sg * dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
-      const double cu = v + decay * sh.cu[b];
+      double cu;
+      if constexpr (sizeof(WT) == 2) {
+        // reduced-precision engine: the hardware's FP32 log2 / exp2 (1 ulp) on |A|^2 taken apart into exponent and
+        // mantissa in FP64, so that the tiny energies of silent bands do not underflow; the slope filter as an
+        // FP32 scan (with the shipped coefficients it forgets its past within two steps)
+        const double p = re[i] * re[i] + im[i] * im[i];
+        const float l2 = (float)__builtin_amdgcn_frexp_exp(p) + __builtin_amdgcn_logf((float)__builtin_amdgcn_frexp_mant(p));
+        const float ex = fminf((float)(4. * kLnDist / kLn2), fmaf((float)kC1, l2, (float)(c0[i] * (1. / kLn2))));
+        const float dist_s = __builtin_amdgcn_exp2f(p == 0. ? -__builtin_inff() : ex);
+        const float v = wave_prefix_geometric((float)sg * dist_s, (float)kM1, (float)kM2, (float)kM4, (float)kM8,
+                                              (float)kM16, (float)decay_row, lane);
+        cu = (double)fmaf((float)decay, (float)sh.cu[b], v);
+      } else {
+        const double dist_s = exp_fast(fmin(4. * kLnDist, c0[i] + kC1 * log_nonneg(re[i] * re[i] + im[i] * im[i])));
+        const double v = wave_prefix_geometric(sg * dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
+        cu = v + decay * sh.cu[b];
+      }
       const double carry = __shfl(cu, nvs - 1, 64);
       if (lane == 0) sh.cu[b] = carry;                               // only this wave touches cu[b]
       cuv[i] = cu;
     }
     FB_MARK(5);
-    switch (wv) {
-      case 0: spread_up<0, WT>(sh, re, im, cuv, lane); break;
-      case 1: spread_up<1, WT>(sh, re, im, cuv, lane); break;
-      case 2: spread_up<2, WT>(sh, re, im, cuv, lane); break;
-      default: spread_up<3, WT>(sh, re, im, cuv, lane); break;
+    if constexpr (sizeof(WT) == 2) {
+      switch (wv) {
+        case 0: spread_up_f32<0, WT>(sh, re, im, cuv, lane); break;
+        case 1: spread_up_f32<1, WT>(sh, re, im, cuv, lane); break;
+        case 2: spread_up_f32<2, WT>(sh, re, im, cuv, lane); break;
+        default: spread_up_f32<3, WT>(sh, re, im, cuv, lane); break;
+      }
+    } else {
+      switch (wv) {
+        case 0: spread_up<0, WT>(sh, re, im, cuv, lane); break;
+        case 1: spread_up<1, WT>(sh, re, im, cuv, lane); break;
+        case 2: spread_up<2, WT>(sh, re, im, cuv, lane); break;
+        default: spread_up<3, WT>(sh, re, im, cuv, lane); break;
+      }
     }
     FB_MARK(6);
     __syncthreads();
@@ -906,6 +960,20 @@ __global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned
   }
 }
 
+// The kernels proper.  Two workgroups per CU either way (LDS); the default arithmetic's kernel is also held to
+// 200 registers -- amdgpu_num_vgpr counts architectural registers and the compiler doubles it on this unified
+// register file -- so that two of its waves leave a SIMD room for a wave of fb_hp_kernel (102 registers): the
+// high-pass walk of the NEXT launch has to run beside the bank, or the bank waits for it (measured: with 212
+// registers the bank kernel was as fast and the advanced pass 55 ms longer).
+template <typename M>
+__global__ __launch_bounds__(256, 2) void fb_bank_kernel(FbFrontArgs a, unsigned n_signals) {
+  fb_bank_body<M>(a, n_signals);
+}
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(100))) void fb_bank_kernel_h3(FbFrontArgs a,
+                                                                                                unsigned n_signals) {
+  fb_bank_body<MfmaH3>(a, n_signals);
+}
+
 hipError_t launch_fb_hp(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream) {
   const unsigned n_signals = n_pairs * a.channels * 2;
   if (n_signals == 0 || a.blocks_per_launch == 0) return hipSuccess;
@@ -919,7 +987,7 @@ hipError_t launch_fb_bank(const FbFrontArgs& a, unsigned n_pairs, hipStream_t st
   if (a.fir_fp64 == 1)
     hipLaunchKernelGGL(fb_bank_kernel<MfmaF64>, dim3(n_signals), dim3(256), 0, stream, a, n_signals);
   else if (a.fir_fp64 == 2)
-    hipLaunchKernelGGL(fb_bank_kernel<MfmaH3>, dim3(n_signals), dim3(256), 0, stream, a, n_signals);
+    hipLaunchKernelGGL(fb_bank_kernel_h3, dim3(n_signals), dim3(256), 0, stream, a, n_signals);
   else
     hipLaunchKernelGGL(fb_bank_kernel<MfmaF32>, dim3(n_signals), dim3(256), 0, stream, a, n_signals);
   return hipGetLastError();

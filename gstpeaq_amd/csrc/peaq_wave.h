@@ -181,6 +181,25 @@ __device__ __forceinline__ double wave_prefix_geometric(double v, double m1, dou
   return fma(wl, row == 0 ? 0. : row == 1 ? t0 : row == 2 ? t1 : t2, v);
 }
 
+// the same in FP32 (one DPP move per step instead of two, 2-cycle arithmetic): for recurrences that forget
+// their past within a few steps
+template <int CTRL>
+__device__ __forceinline__ float dpp_f0(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_prefix_geometric(float v, float m1, float m2, float m4, float m8, float m16, float wl,
+                                                       int lane) {
+  v = fmaf(m1, dpp_f0<kDppRowShr + 1>(v), v);
+  v = fmaf(m2, dpp_f0<kDppRowShr + 2>(v), v);
+  v = fmaf(m4, dpp_f0<kDppRowShr + 4>(v), v);
+  v = fmaf(m8, dpp_f0<kDppRowShr + 8>(v), v);
+  const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
+  const float t1 = fmaf(m16, t0, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31)));
+  const float t2 = fmaf(m16, t1, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47)));
+  const int row = lane >> 4;
+  return fmaf(wl, row == 0 ? 0.f : row == 1 ? t0 : row == 2 ? t1 : t2, v);
+}
+
 template <typename OP>
 __device__ __forceinline__ double wave_reduce_d(double v, OP op) {
   v = op(v, dpp_d<kDppXor1>(v));
