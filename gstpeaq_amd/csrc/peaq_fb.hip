@@ -191,9 +191,9 @@ constexpr int kWinCols = (kWin + 31) / 32;          // 105
 // (the old stride 106 made them overlap on 12 banks: 30 % of the LDS cycles were conflicts)
 constexpr int kWinRow = 112;
 static_assert(kWinRow > kWinCols && kWinRow % 32 == 16, "window rows: long enough, and two rows apart = 32 banks");
-// A[band][time] row stride.  (Rows of 66 / 68 / 72 doubles take the LDS bank-conflict share of the kernel from
-// 15 % to 11 % of the active LDS cycles and change its run time by nothing measurable: 64 stays.)
-constexpr int kACols = 64;
+// A[band][time] row stride: an odd number of doubles, so that the (band, block) items of phase 4 -- lanes on
+// different rows at the same column -- do not all fall on one pair of banks.
+constexpr int kACols = 65;
 
 // window sample with uniform index part u (the lane adds its time point): row u mod 32,
 // column u div 32 -- lanes (time points 32 samples apart) then sit in consecutive columns
@@ -887,48 +887,43 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     }
     __syncthreads();
     FB_MARK(8);
-    // ---- phase 4: rectification + backward masking at block rate (fbearmodel.c:357-382);
-    // one (band, block) per thread --------------------------------------------------------------------
-    for (int item = tid; item < kFbBands * kTileBlocks; item += 256) {
-      const int b = item / kTileBlocks, blk = item - b * kTileBlocks;
-      // E0 of sub-sample s (negative: previous tile)
-      auto e0 = [&](int s) {
-        if (s < 0) return sh.hist[b][10 + s];
-        const double x = sh.a.re[b][s], y = sh.a.im[b][s];
-        return x * x + y * y;
-      };
-      const int s_new = 6 * blk + 5;                 // newest sub-sample of the block
-      double e1 = 0.;
+    // ---- phase 4: rectification + backward masking at block rate (fbearmodel.c:357-382), wave-local: a
+    // wave takes the ten bands it carried through phase 2, first E0 = re^2 + im^2 for all time points (lane =
+    // time, written over re), then one (band, block) per lane: eleven reads of E0, no barrier in between ------
 #pragma unroll
-      for (int i = 0; i < 5; ++i) e1 += (e0(s_new - i) + e0(s_new - 10 + i)) * fb->back_mask[i];
-      e1 += e0(s_new - 5) * fb->back_mask[5];
-      sh.e1[b][blk] = e1;
+    for (int i = 0; i < 10; ++i) {
+      const int b = wave_band(wv, i);
+      const double x = sh.a.re[b][lane], y = sh.a.im[b][lane];
+      sh.a.re[b][lane] = x * x + y * y;
     }
-    __syncthreads();
-    FB_MARK(9);
-    // history for the next tile: the 10 newest VALID sub-samples, oldest first
-    // (400 (band, slot) items on 256 threads: two per thread)
+    wave_lds_fence();
     double hnew[2] = {0., 0.};
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
-      const int item = tid + 256 * rep;
-      if (item < kFbBands * 10) {
-        const int b = item / 10, k = item - b * 10;
-        const int s = nvs - 10 + k;
-        if (s < 0) {
-          hnew[rep] = sh.hist[b][10 + s];
-        } else {
-          const double x = sh.a.re[b][s], y = sh.a.im[b][s];
-          hnew[rep] = x * x + y * y;
-        }
+      const int item = lane + 64 * rep;              // 100 (band, block) / (band, history slot) items per wave
+      if (item < 100) {
+        const int i = item / 10, k = item - 10 * i;
+        const int b = wave_band(wv, i);
+        // E0 of sub-sample s (negative: previous tile)
+        auto e0 = [&](int s) { return s < 0 ? sh.hist[b][10 + s] : sh.a.re[b][s]; };
+        const int s_new = 6 * k + 5;                 // newest sub-sample of block k
+        double e1 = 0.;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) e1 += (e0(s_new - t) + e0(s_new - 10 + t)) * fb->back_mask[t];
+        e1 += e0(s_new - 5) * fb->back_mask[5];
+        sh.e1[b][k] = e1;
+        // history for the next tile: the 10 newest VALID sub-samples, oldest first
+        hnew[rep] = e0(nvs - 10 + k);
       }
     }
-    __syncthreads();
+    wave_lds_fence();
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
-      const int item = tid + 256 * rep;
-      if (item < kFbBands * 10) sh.hist[item / 10][item % 10] = hnew[rep];
+      const int item = lane + 64 * rep;
+      if (item < 100) sh.hist[wave_band(wv, item / 10)][item % 10] = hnew[rep];
     }
+    __syncthreads();
+    FB_MARK(9);
     FB_MARK(10);
     // ---- phase 5: internal noise + forward masking (fbearmodel.c:385-394).  The recurrence along
     // the blocks is walked by one thread per band into LDS; then all threads write the records --------
