@@ -88,21 +88,26 @@ void peaq_settings_default (peaq_settings *s);
 int peaq_ctx_set_settings (peaq_ctx *ctx, const peaq_settings *s);
 int peaq_ctx_get_settings (const peaq_ctx *ctx, peaq_settings *s);
 
-/* Advanced version only: which matrix instruction evaluates the 40 complex FIR filters of the
- * filter-bank ear model (fbearmodel.c:399-435).  Default 0 = FP32 (v_mfma_f32_16x16x4_f32, twice the
- * rate): measured max |dODG| against the all-FP64 path 5e-8 over 39 advanced cases
- * (profiles/r02_precision_ledger.json).  1 = FP64 (v_mfma_f64_16x16x4_f64), which follows the
- * reference's double arithmetic to 1e-9 per block; also selected by the environment variable
- * PEAQ_AMD_FIR_FP64=1 at context creation.  Everything else is FP64 either way.  Applies to the
- * launches that follow. */
-int peaq_ctx_set_fir_fp64 (peaq_ctx *ctx, int enable);
-int peaq_ctx_get_fir_fp64 (const peaq_ctx *ctx);
-/* The three arithmetics of that FIR bank (same entry points otherwise): */
-#define PEAQ_FIR_F32   0   /* v_mfma_f32_16x16x4_f32 */
-#define PEAQ_FIR_F64   1   /* v_mfma_f64_16x16x4_f64: what peaq_ctx_set_fir_fp64(ctx, 1) selects */
-#define PEAQ_FIR_F16X3 2   /* v_mfma_f32_16x16x32_f16 on operands split into two FP16 parts, three products per term */
+/* Advanced version only: the arithmetic of the filter-bank ear model's front half
+ * (fbearmodel.c:327-435: the 40 complex FIR filters, the level-dependent slopes, the upward spreading).
+ *   PEAQ_FIR_F16X3 (default): the FIR bank on v_mfma_f32_16x16x32_f16 with signal and coefficients split
+ *       into a high and a low FP16 part and three products per term (about 22 bits), FP32 accumulation;
+ *       slopes and upward spreading in FP32.  Measured max |dODG| against the all-FP64 path 9e-8 over 39
+ *       advanced cases (profiles/r02_precision_ledger.json).  Samples more than 30 dB above full scale
+ *       saturate in the FIR's operands.
+ *   PEAQ_FIR_F32: the FIR bank on v_mfma_f32_16x16x4_f32 (5e-8), everything after it FP64.
+ *   PEAQ_FIR_F64: v_mfma_f64_16x16x4_f64, follows the reference's double arithmetic to 1e-9 per block;
+ *       peaq_ctx_set_fir_fp64(ctx, 1) and the environment variable PEAQ_AMD_FIR_FP64=1 select it too
+ *       (peaq_ctx_set_fir_fp64(ctx, 0) returns to the default).
+ * PEAQ_AMD_FIR=f16x3|f32|f64 in the environment sets the mode at context creation.  The basic version and
+ * everything downstream of the spreading are FP64 in every mode.  Applies to the launches that follow. */
+#define PEAQ_FIR_F32   0
+#define PEAQ_FIR_F64   1
+#define PEAQ_FIR_F16X3 2
 int peaq_ctx_set_fir_mode (peaq_ctx *ctx, int mode);
 int peaq_ctx_get_fir_mode (const peaq_ctx *ctx);
+int peaq_ctx_set_fir_fp64 (peaq_ctx *ctx, int enable);
+int peaq_ctx_get_fir_fp64 (const peaq_ctx *ctx);
 
 /* ---- session API ------------------------------------------------------------
  * Replaces, per element instance: g_object_new(PEAQ_TYPE_FFTEARMODEL /
