@@ -93,3 +93,25 @@ def test_fullsize_pairs_fp32_vs_fp64_fir(fp32_ctx):
     for x, y in zip(a, b):
         np.testing.assert_allclose(x["movs"], y["movs"], rtol=2e-6, atol=1e-9)
     print(f"{fp32_ctx.fir_mode()} vs FP64 FIR on 32 ten-second pairs: max |dODG| {d:.3e}")
+
+
+def test_split_fp16_operands_saturate_instead_of_overflowing():
+    """Float input far beyond full scale (the WAV float formats allow it): the FP16 operands of the default
+    FIR hold 30 dB of headroom above full scale and saturate beyond it (Window<_Float16>::put) -- results
+    stay finite, and up to the headroom they follow the FP64 path."""
+    import torch
+    import gstpeaq_amd
+    import gpu_common
+    c = gstpeaq_amd.Context(0)
+    assert c.fir_mode() == "f16x3"
+    ref, test = case_defs.make_inputs(dict(kind="synth", seed=3, channels=2, n=48000))
+    for gain, must_match in ((20.0, True), (1000.0, False)):          # +26 dB: inside the headroom; +60 dB: beyond
+        r = torch.from_numpy(ref[None] * np.float32(gain)).cuda()
+        t = torch.from_numpy(test[None] * np.float32(gain)).cuda()
+        got = gstpeaq_amd.batch_run(c, 1, r, t)[0]
+        assert np.isfinite(got["odg"]) and np.all(np.isfinite(got["movs"][:5])), (gain, got)
+        if must_match:
+            exp = gstpeaq_amd.batch_run(gpu_common.ctx(), 1, r, t)[0]
+            # (a 26 dB louder presentation: the level-dependent spreading reaches further, and with it its FP32 rounding)
+            assert abs(got["odg"] - exp["odg"]) <= 5e-6, (gain, got["odg"], exp["odg"])
+    c.close()
