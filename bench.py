@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import gstpeaq_amd
     from gstpeaq_amd import parallel
@@ -400,10 +401,24 @@ def main():
                    "dtype": "f64, FIR bank of the filter-bank ear model on " + {
                        "f64": "v_mfma_f64", "f32": "v_mfma_f32 (max |dODG| 5e-8 vs all-FP64, profiles/r02_precision_ledger.json)",
                        "f16x3": "v_mfma_f32_16x16x32_f16 with both operands split into two FP16 parts, three products per term "
-                                "(max |dODG| 1e-7 vs all-FP64, profiles/r02_precision_ledger.json)"}[ctx.fir_mode()],
+                                "and FP32 slopes / upward spreading (max |dODG| vs the all-FP64 engine: 5e-7 over the 78 cases "
+                                "of profiles/r02_precision_ledger.json; over this run's pairs see all_fp64)"}[ctx.fir_mode()],
                    "roofline": filterbank_roofline(ma),
                    "odg_mean": float(ma["gathered"][:, 12][~torch.isnan(ma["gathered"][:, 12])].mean().item())}
         rows_adv = ma["rows"]
+        # the same workload with every stage in FP64 (PEAQ_FIR_F64), so that the line also carries the rate at the
+        # reference's own precision and the deviation of the default engine from it on these very pairs
+        if ctx.fir_mode() != "f64":
+            mode = ctx.fir_mode()
+            ctx.set_fir_mode("f64")
+            m64 = measure(True, min(adv_steps, 2), 1)
+            ctx.set_fir_mode(mode)
+            if rank == 0:
+                a, b = ma["rows"][:, 12], m64["rows"][:, 12]
+                ok = ~(np.isnan(a) | np.isnan(b))
+                adv["all_fp64"] = {"value": m64["fp_all"] * min(adv_steps, 2) / m64["timed"], "unit": "frame-pairs/s",
+                                   "odg_max_abs_delta_default_vs_fp64": float(np.max(np.abs(a[ok] - b[ok]))) if ok.any() else None,
+                                   "pairs": int(ok.sum())}
 
     # ---- CPU legs: rank 0, single GPU only (they would disturb the other ranks' timing otherwise) ------
     if rank == 0 and not args.no_cpu_baseline and world == 1:

@@ -92,8 +92,9 @@ int peaq_ctx_get_settings (const peaq_ctx *ctx, peaq_settings *s);
  * (fbearmodel.c:327-435: the 40 complex FIR filters, the level-dependent slopes, the upward spreading).
  *   PEAQ_FIR_F16X3 (default): the FIR bank on v_mfma_f32_16x16x32_f16 with signal and coefficients split
  *       into a high and a low FP16 part and three products per term (about 22 bits), FP32 accumulation;
- *       slopes and upward spreading in FP32.  Measured max |dODG| against the all-FP64 path 9e-8 over 39
- *       advanced cases (profiles/r02_precision_ledger.json).  Samples more than 30 dB above full scale
+ *       slopes and upward spreading in FP32.  Measured max |dODG| against the all-FP64 path 5e-7 over 39
+ *       advanced cases (profiles/r02_precision_ledger.json), 6e-6 over 4096 ten-second pairs (bench.py,
+ *       advanced.all_fp64).  Samples more than 30 dB above full scale
  *       saturate in the FIR's operands.
  *   PEAQ_FIR_F32: the FIR bank on v_mfma_f32_16x16x4_f32 (5e-8), everything after it FP64.
  *   PEAQ_FIR_F64: v_mfma_f64_16x16x4_f64, follows the reference's double arithmetic to 1e-9 per block;
