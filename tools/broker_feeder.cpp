@@ -7,8 +7,11 @@
 // then test, so that all N sessions are mid-stream at the same time; the broker's
 // own tick thread batches whatever became ready.  At the end every session is
 // flushed (do_flush, gstpeaq.c:716-745) and its result compared with the batch
-// path run on the SAME seeded pairs: bit-equal in the basic version, 1e-9
-// relative in the advanced one (LDS-atomic summation order).
+// path run on the SAME seeded pairs: bit-equal in the basic version; in the
+// advanced one 1e-9 relative with the all-FP64 engine (LDS-atomic summation
+// order) and 5e-6 with the default one, whose FP32 slope filter
+// rounds differently when a stream is cut into other launches (48 blocks per
+// tick here, 840 per launch in the batch path).
 //
 //   broker_feeder [--sessions N] [--seconds S] [--threads T] [--chunk SAMPLES]
 //                 [--channels C] [--advanced] [--period-us P] [--seed0 K] [--ragged]
@@ -149,7 +152,7 @@ int main(int argc, char** argv) {
   CHECK_PEAQ(peaq_broker_stop(br));
 
   // ---- compare -------------------------------------------------------------------------------------
-  const double rtol = advanced ? 1e-9 : 0.;
+  const double rtol = !advanced ? 0. : peaq_ctx_get_fir_mode(ctx) == PEAQ_FIR_F64 ? 1e-9 : 5e-6;
   const int n_movs = advanced ? PEAQ_MOVS_ADVANCED : PEAQ_MOVS_BASIC;
   int mismatches = 0, nan_odg = 0;
   double frames = 0., max_dodg = 0.;
