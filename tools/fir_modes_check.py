@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Quick look at the three arithmetics of the advanced version's filter bank (include/peaq_amd.h PEAQ_FIR_*):
+per-block excitation of the reduced ones against the FP64 one on three signals, and max |dODG| of each against
+the reference's 27 advanced goldens.  Development tool (the tests proper: tests/test_gpu_fir_modes.py; the
+ledger: tools/precision_ledger.py).  Needs an MI355X."""
 import sys, json, numpy as np, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import gstpeaq_amd, cases as case_defs, oracle_lib as orc
