@@ -9,6 +9,9 @@ not exist on the GPU box, the committed fixtures travel instead.
                                       element on tests/cases.py:e2e_cases()
   tests/golden/ref_stages.npz         per-frame ear-model outputs (public getters)
   tests/golden/ref_tables.json        band tables (Appendix C of SURVEY.md, in full)
+  tests/golden/ref_e2e_level.json     the same for other playback levels      (python tools/make_golden.py levels)
+  tests/golden/ref_e2e_settings.json  the same for the reference built with each settings.h switch flipped
+                                      (oracle/Makefile ref_variants)          (python tools/make_golden.py settings)
 """
 import json
 import os
