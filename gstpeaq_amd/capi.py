@@ -101,6 +101,7 @@ def load_library():
     L.peaq_debug_backend.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp]
     L.peaq_batch_run.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, C.c_size_t,
                                  u32p, u32p, C.c_uint32, vp, vp]
+    L.peaq_run_pair.argtypes = [vp, C.c_int, C.c_int, C.c_double, fp, C.c_size_t, fp, C.c_size_t, dp]
     L.peaq_batch_workspace_bytes.restype = C.c_size_t
     L.peaq_batch_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32]
     L.peaq_batch_last_timing.argtypes = [vp, C.POINTER(_Timing)]
@@ -329,6 +330,20 @@ def batch_run(ctx, advanced, ref, test, n_ref=None, n_test=None, playback_level=
     torch.cuda.synchronize(ref.device)
     rows = results.cpu().numpy()
     return [_result_dict(r, advanced) for r in rows]
+
+
+def run_pair(ctx, advanced, ref, test, playback_level=92.0):
+    """one whole pair from host memory (peaq_run_pair): ref/test numpy float32 [n, channels]"""
+    ref = np.ascontiguousarray(ref, dtype=np.float32)
+    test = np.ascontiguousarray(test, dtype=np.float32)
+    ch = ref.shape[1]
+    assert test.shape[1] == ch
+    out = np.zeros(RESULT_DOUBLES)
+    _check(ctx.L.peaq_run_pair(ctx.h, int(bool(advanced)), ch, float(playback_level),
+                               ref.ctypes.data_as(C.POINTER(C.c_float)), len(ref),
+                               test.ctypes.data_as(C.POINTER(C.c_float)), len(test),
+                               out.ctypes.data_as(C.POINTER(C.c_double))))
+    return _result_dict(out, bool(advanced))
 
 
 def synth_fill(ctx, seed0, n_pairs, channels, n_samples, device="cuda:0", stream=None, out=None):

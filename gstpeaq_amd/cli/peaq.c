@@ -260,32 +260,46 @@ main (int argc, char **argv)
     m->samples = st;
     m->channels = 2;
   }
-  if (peaq_ctx_create (getenv ("PEAQ_AMD_DEVICE") ? atoi (getenv ("PEAQ_AMD_DEVICE")) : 0, &ctx) != PEAQ_OK ||
-      peaq_session_create (ctx, advanced, ref.channels, level, &s) != PEAQ_OK) {
+  if (peaq_ctx_create (getenv ("PEAQ_AMD_DEVICE") ? atoi (getenv ("PEAQ_AMD_DEVICE")) : 0, &ctx) != PEAQ_OK) {
     printf ("Error: peaq engine could not be instantiated - %s\n", peaq_last_error ());
     return 2;
   }
-  /* feed like two streaming threads would: alternating buffers of 4096 samples */
-  for (pos = 0; pos < ref.frames || pos < test.frames; pos += 4096) {
-    rc = PEAQ_OK;
-    if (pos < ref.frames)
-      rc = peaq_session_push (s, 0, ref.samples + pos * ref.channels,
-          ref.frames - pos < 4096 ? ref.frames - pos : 4096);
-    if (rc == PEAQ_OK && pos < test.frames)
-      rc = peaq_session_push (s, 1, test.samples + pos * test.channels,
-          test.frames - pos < 4096 ? test.frames - pos : 4096);
-    if (rc != PEAQ_OK) {
+  if (!getenv ("PEAQ_AMD_CLI_STREAM")) {
+    /* both files are in memory: one call, every kernel sees the whole stream (a 5-minute pair of the advanced
+     * version: 2 s instead of the 4 s of buffer-by-buffer sessions) */
+    if (peaq_run_pair (ctx, advanced, ref.channels, level, ref.samples, ref.frames, test.samples, test.frames, &r) !=
+        PEAQ_OK) {
       printf ("Error: %s\n", peaq_last_error ());
       return 2;
     }
-  }
-  if (peaq_session_flush (s) != PEAQ_OK || peaq_session_results (s, &r) != PEAQ_OK) {
-    printf ("Error: %s\n", peaq_last_error ());
-    return 2;
+  } else {
+    /* PEAQ_AMD_CLI_STREAM=1: feed a session like two streaming threads would, alternating buffers of 4096
+     * samples (what the `peaq` element does) */
+    if (peaq_session_create (ctx, advanced, ref.channels, level, &s) != PEAQ_OK) {
+      printf ("Error: peaq engine could not be instantiated - %s\n", peaq_last_error ());
+      return 2;
+    }
+    for (pos = 0; pos < ref.frames || pos < test.frames; pos += 4096) {
+      rc = PEAQ_OK;
+      if (pos < ref.frames)
+        rc = peaq_session_push (s, 0, ref.samples + pos * ref.channels,
+            ref.frames - pos < 4096 ? ref.frames - pos : 4096);
+      if (rc == PEAQ_OK && pos < test.frames)
+        rc = peaq_session_push (s, 1, test.samples + pos * test.channels,
+            test.frames - pos < 4096 ? test.frames - pos : 4096);
+      if (rc != PEAQ_OK) {
+        printf ("Error: %s\n", peaq_last_error ());
+        return 2;
+      }
+    }
+    if (peaq_session_flush (s) != PEAQ_OK || peaq_session_results (s, &r) != PEAQ_OK) {
+      printf ("Error: %s\n", peaq_last_error ());
+      return 2;
+    }
+    peaq_session_destroy (s);
   }
   printf ("Objective Difference Grade: %.3f\n", r.odg);
   printf ("Distortion Index: %.3f\n", r.di);
-  peaq_session_destroy (s);
   peaq_ctx_destroy (ctx);
   free (ref.samples);
   free (test.samples);

@@ -548,6 +548,38 @@ extern "C" int peaq_batch_run(peaq_ctx* c, int advanced, int channels, double le
   return PEAQ_OK;
 }
 
+// One whole (ref, test) pair from host memory: the batch path with n_pairs = 1 -- for a caller that holds both
+// files (the CLI).  The same frames and blocks as a session fed with the same samples (count_frames), but every
+// kernel sees the whole stream: one front-end launch, the filter-bank path pipelined over its three streams.
+extern "C" int peaq_run_pair(peaq_ctx* c, int advanced, int channels, double level_db, const float* ref, size_t n_ref,
+                             const float* test, size_t n_test, peaq_result* out) {
+  if (!c || !out) return fail(PEAQ_ERR_ARG, "peaq_run_pair: NULL argument");
+  if (channels != 1 && channels != 2) return fail(PEAQ_ERR_ARG, "peaq_run_pair: channels must be 1 or 2");
+  if ((n_ref && !ref) || (n_test && !test)) return fail(PEAQ_ERR_ARG, "peaq_run_pair: NULL samples");
+  if (n_ref > 0xFFFFFFFFu || n_test > 0xFFFFFFFFu) return fail(PEAQ_ERR_ARG, "peaq_run_pair: more than 2^32 samples");
+  HIP_TRY(hipSetDevice(c->device));
+  size_t stride = std::max<size_t>(std::max(n_ref, n_test), 2);
+  stride += stride & 1;                              // 8-byte rows: the frame loads are dword pairs
+  TmpBuf d_ref, d_test, d_n, d_res;
+  const size_t bytes = stride * channels * sizeof(float);
+  HIP_TRY(d_ref.reserve(bytes));
+  HIP_TRY(d_test.reserve(bytes));
+  HIP_TRY(d_n.reserve(2 * sizeof(uint32_t)));
+  HIP_TRY(d_res.reserve(sizeof(peaq_result)));
+  HIP_TRY(hipMemset(d_ref.p, 0, bytes));
+  HIP_TRY(hipMemset(d_test.p, 0, bytes));
+  if (n_ref) HIP_TRY(hipMemcpy(d_ref.p, ref, n_ref * channels * sizeof(float), hipMemcpyHostToDevice));
+  if (n_test) HIP_TRY(hipMemcpy(d_test.p, test, n_test * channels * sizeof(float), hipMemcpyHostToDevice));
+  const uint32_t h_n[2] = {(uint32_t)n_ref, (uint32_t)n_test};
+  HIP_TRY(hipMemcpy(d_n.p, h_n, sizeof h_n, hipMemcpyHostToDevice));
+  const int rc = peaq_batch_run(c, advanced, channels, level_db, 1, d_ref.as<float>(), d_test.as<float>(), stride,
+                                d_n.as<uint32_t>(), d_n.as<uint32_t>() + 1, 0, d_res.as<peaq_result>(), nullptr);
+  if (rc != PEAQ_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, d_res.p, sizeof(peaq_result), hipMemcpyDeviceToHost));
+  return PEAQ_OK;
+}
+
 static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double level_db, int n_pairs, const float* d_ref,
                             const float* d_test, size_t pair_stride, const uint32_t* n_ref, const uint32_t* n_test,
                             uint32_t n_uniform, peaq_result* d_results, hipStream_t stream) {

@@ -214,6 +214,12 @@ typedef struct {
 } peaq_batch_timing;
 int peaq_batch_last_timing (peaq_ctx *ctx, peaq_batch_timing *out);
 
+/* One whole pair from HOST memory (interleaved F32, n samples per channel each): upload + the batch path
+ * with one pair + result.  For callers that hold both signals completely (gstpeaq_amd/cli/peaq.c); same
+ * framing, flush and results as a session fed with the same samples (gstpeaq.c:596-611, 716-745). */
+int peaq_run_pair (peaq_ctx *ctx, int advanced, int channels, double playback_level_db,
+                   const float *ref, size_t n_ref, const float *test, size_t n_test, peaq_result *out);
+
 /* ---- synthetic workload (include/peaq_synth.h on the device) -------------
  * Fills d_ref/d_test [n_pairs][pair_stride][channels] with the seeded pairs
  * seed0 .. seed0+n_pairs-1, n_samples each.  Benchmark / test utility. */

@@ -84,12 +84,15 @@ def test_cli_on_wav_files(tmp_path, advanced):
     rq = write_wav16(tmp_path / "ref.wav", ref)
     tq = write_wav16(tmp_path / "test.wav", test)
     exp = orc.run_pair(advanced, rq, tq)
-    out = subprocess.run([str(gst_env.CLI), "--advanced" if advanced else "--basic",
-                          str(tmp_path / "ref.wav"), str(tmp_path / "test.wav")], capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout + out.stderr
-    lines = out.stdout.strip().splitlines()
-    assert lines[-2] == "Objective Difference Grade: %.3f" % exp["odg"]      # peaq.c:217-220
-    assert lines[-1] == "Distortion Index: %.3f" % exp["di"]
+    import os
+    # whole files in one call (peaq_run_pair, the default) and buffer by buffer through a session
+    for env in (dict(os.environ), dict(os.environ, PEAQ_AMD_CLI_STREAM="1")):
+        out = subprocess.run([str(gst_env.CLI), "--advanced" if advanced else "--basic",
+                              str(tmp_path / "ref.wav"), str(tmp_path / "test.wav")], capture_output=True, text=True, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        lines = out.stdout.strip().splitlines()
+        assert lines[-2] == "Objective Difference Grade: %.3f" % exp["odg"]      # peaq.c:217-220
+        assert lines[-1] == "Distortion Index: %.3f" % exp["di"]
 
 
 def test_many_elements_share_the_broker():

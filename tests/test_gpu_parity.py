@@ -263,3 +263,16 @@ def test_playback_level_matches_reference_goldens(gpu, advanced):
         b.close()
     with pytest.raises(gstpeaq_amd.PeaqError):                     # property range 0..130 (gstpeaq.c:275-281)
         gstpeaq_amd.Session(gpu.ctx(), advanced, 2, playback_level=131.0)
+
+
+def test_run_pair_from_host_memory_equals_the_goldens(gpu):
+    """peaq_run_pair (upload + one-pair batch + result): ragged, sub-frame, silent and empty pairs included"""
+    import gstpeaq_amd
+    for adv in (0, 1):
+        for rec in gpu.e2e_records(adv)[:40]:
+            ref, test = case_defs.make_inputs(rec["case"])
+            got = gstpeaq_amd.run_pair(gpu.ctx(), adv, ref, test)
+            gpu.compare_result(got, rec, rtol=1e-7, atol=1e-9, odg_atol=1e-7)
+    empty = np.zeros((0, 2), dtype=np.float32)
+    got = gstpeaq_amd.run_pair(gpu.ctx(), 0, empty, empty)
+    assert got["frames"] == 0 and np.isnan(got["odg"])
