@@ -81,3 +81,19 @@ def test_python_layer_refuses_to_run_without_the_library(monkeypatch, tmp_path):
     monkeypatch.setattr(capi, "library_path", lambda: tmp_path / "libpeaq_amd.so")
     with pytest.raises(capi.PeaqError):
         capi.load_library()
+
+
+def test_settings_default_are_the_reference_s_shipped_values():
+    """peaq_settings_default needs no device: settings.h:47-97 as the reference ships them"""
+    import ctypes as C
+    import gstpeaq_amd
+    from gstpeaq_amd.capi import Settings
+    L = gstpeaq_amd.load_library()
+    st = Settings()
+    L.peaq_settings_default(C.byref(st))
+    assert [getattr(st, k) for k, _ in Settings._fields_] == [1, 0, 1, 0, 0, 0]
+    # without a GPU every entry point that needs one fails loudly (no CPU fallback)
+    import torch
+    if not torch.cuda.is_available():
+        h = C.c_void_p()
+        assert L.peaq_ctx_create(0, C.byref(h)) != 0 and b"HIP device" in L.peaq_last_error()
