@@ -5,7 +5,7 @@ the reference's 27 advanced goldens.  Development tool (the tests proper: tests/
 ledger: tools/precision_ledger.py).  Needs an MI355X."""
 import sys, json, numpy as np, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
-import gstpeaq_amd, cases as case_defs, oracle_lib as orc
+import gstpeaq_amd, cases as case_defs
 ctx = gstpeaq_amd.Context(0)
 for case in [dict(kind="synth", seed=5, channels=1, n=40000), dict(kind="ats", wave_ref="saw", wave_test="triangle", n=32768, channels=1),
              dict(kind="synth", seed=6, channels=2, n=30000, test_trim=900)]:
