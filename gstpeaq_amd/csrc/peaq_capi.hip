@@ -185,16 +185,28 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
       const size_t end = std::min(spec.find(',', pos), spec.size());
       std::string item = spec.substr(pos, end - pos);
       pos = end + 1;
+      auto trim = [](std::string t) {
+        const size_t a = t.find_first_not_of(" \t"), b = t.find_last_not_of(" \t");
+        return a == std::string::npos ? std::string() : t.substr(a, b - a + 1);
+      };
+      item = trim(item);
+      if (item.empty()) continue;
       const size_t eq = item.find('=');
-      std::string key = item.substr(0, eq);
+      std::string key = trim(item.substr(0, eq));
+      const std::string val = eq == std::string::npos ? std::string() : trim(item.substr(eq + 1));
       for (char& ch : key) ch = (char)std::tolower((unsigned char)ch);
       bool known = false;
       for (auto& t : tab)
         if (key == t.name) {
-          *t.field = eq != std::string::npos && std::atoi(item.c_str() + eq + 1) != 0;
+          // a bare NAME is refused rather than read as 0 (the opposite of what its author meant)
+          if (val != "0" && val != "1") {
+            delete c;
+            return fail(PEAQ_ERR_ARG, "PEAQ_AMD_SETTINGS: '" + item + "': write NAME=0 or NAME=1");
+          }
+          *t.field = val == "1";
           known = true;
         }
-      if (!known && !item.empty()) {
+      if (!known) {
         delete c;
         return fail(PEAQ_ERR_ARG, "PEAQ_AMD_SETTINGS: unknown switch '" + item + "' (settings.h macro names, NAME=0|1)");
       }
@@ -228,7 +240,10 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
     // the back end is the latency-bound consumer of the pipeline: give its stream priority
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIP_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi));
+    int prio = hi;
+    if (const char* e = std::getenv("PEAQ_AMD_BE_STREAM_PRIO"))   // development: "lo" | "hi" | "none"
+      prio = e[0] == 'l' ? lo : e[0] == 'n' ? (lo + hi) / 2 : hi;
+    HIP_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio));
   }
   HIP_TRY(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->aux3, hipStreamNonBlocking));
@@ -380,6 +395,9 @@ static unsigned frames_per_chunk(int n_pairs, int channels, uint32_t max_frames)
   fc = std::min<size_t>(fc, 64);
   // few pairs: take long chunks so that the launch count stays small
   if ((size_t)max_frames * per_frame <= ((size_t)256 << 20)) fc = max_frames;
+  // the front end takes a work item apart with a 32-bit reciprocal of the frames per launch, exact up to
+  // max_frames_per_launch (launch_frontend refuses more): a 30-minute mono file is two chunks, not one
+  fc = std::min<size_t>(fc, max_frames_per_launch((unsigned)n_pairs));
   return static_cast<unsigned>(std::min<size_t>(fc, std::max<uint32_t>(max_frames, 1)));
 }
 
@@ -560,20 +578,18 @@ extern "C" int peaq_run_pair(peaq_ctx* c, int advanced, int channels, double lev
   HIP_TRY(hipSetDevice(c->device));
   size_t stride = std::max<size_t>(std::max(n_ref, n_test), 2);
   stride += stride & 1;                              // 8-byte rows: the frame loads are dword pairs
-  TmpBuf d_ref, d_test, d_n, d_res;
+  TmpBuf d_ref, d_test, d_res;
   const size_t bytes = stride * channels * sizeof(float);
   HIP_TRY(d_ref.reserve(bytes));
   HIP_TRY(d_test.reserve(bytes));
-  HIP_TRY(d_n.reserve(2 * sizeof(uint32_t)));
   HIP_TRY(d_res.reserve(sizeof(peaq_result)));
   HIP_TRY(hipMemset(d_ref.p, 0, bytes));
   HIP_TRY(hipMemset(d_test.p, 0, bytes));
   if (n_ref) HIP_TRY(hipMemcpy(d_ref.p, ref, n_ref * channels * sizeof(float), hipMemcpyHostToDevice));
   if (n_test) HIP_TRY(hipMemcpy(d_test.p, test, n_test * channels * sizeof(float), hipMemcpyHostToDevice));
-  const uint32_t h_n[2] = {(uint32_t)n_ref, (uint32_t)n_test};
-  HIP_TRY(hipMemcpy(d_n.p, h_n, sizeof h_n, hipMemcpyHostToDevice));
+  const uint32_t h_n[2] = {(uint32_t)n_ref, (uint32_t)n_test};    // peaq_batch_run takes the lengths as HOST arrays
   const int rc = peaq_batch_run(c, advanced, channels, level_db, 1, d_ref.as<float>(), d_test.as<float>(), stride,
-                                d_n.as<uint32_t>(), d_n.as<uint32_t>() + 1, 0, d_res.as<peaq_result>(), nullptr);
+                                h_n, h_n + 1, 0, d_res.as<peaq_result>(), nullptr);
   if (rc != PEAQ_OK) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, d_res.p, sizeof(peaq_result), hipMemcpyDeviceToHost));
@@ -791,7 +807,14 @@ extern "C" int peaq_debug_frontend(peaq_ctx* c, int bands, int channels, double 
   fa.bands = bands == 109 ? c->d_bands109 : c->d_bands55;
   fa.records = d_rec;
   std::vector<double> h_rec((size_t)n_frames * channels * kRecDoubles);
-  hipError_t e = launch_frontend(bands, fa, 1, nullptr);
+  // one pair: launches of at most max_frames_per_launch(1) frames, the records of a launch follow the previous one's
+  hipError_t e = hipSuccess;
+  for (uint32_t f0 = 0; f0 < (uint32_t)n_frames && e == hipSuccess; f0 += max_frames_per_launch(1)) {
+    fa.frame0 = f0;
+    fa.frames_per_launch = std::min<uint32_t>(max_frames_per_launch(1), (uint32_t)n_frames - f0);
+    fa.records = d_rec + (size_t)f0 * channels * kRecDoubles;
+    e = launch_frontend(bands, fa, 1, nullptr);
+  }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipMemcpy(h_rec.data(), d_rec, bytes, hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail(PEAQ_ERR_DEVICE, std::string("peaq_debug_frontend: ") + hipGetErrorString(e));

@@ -54,7 +54,10 @@ constexpr int kOffPw = 0;                     // Pw[776]
 constexpr int kOffScratch = 776;              // 512 doubles
 constexpr int kPwLen = 776;
 constexpr int kLdsDoubles = 2 * kUnitDoubles;
-constexpr int kWavesPerSimd = 3;
+#ifndef PEAQ_FE_WAVES
+#define PEAQ_FE_WAVES 3
+#endif
+constexpr int kWavesPerSimd = PEAQ_FE_WAVES;
 
 // W_32^q = exp(-2 pi i q / 32), q = 0..15
 __device__ constexpr double kW32re[16] = {1., 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
@@ -319,7 +322,11 @@ struct FrameSrc {
 #endif
 
 template <int NB>
-__global__ __launch_bounds__(128, kWavesPerSimd) void frontend_kernel(FrontendArgs a) {
+__global__ __launch_bounds__(128, kWavesPerSimd)
+#ifdef PEAQ_FE_NUM_VGPR
+__attribute__((amdgpu_num_vgpr(PEAQ_FE_NUM_VGPR)))
+#endif
+void frontend_kernel(FrontendArgs a) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63;
   // 0 = reference wave, 1 = test wave; wave-uniform, so keep it (and all that hangs on it) scalar
@@ -884,6 +891,12 @@ hipError_t launch_frontend(int bands, const FrontendArgs& a, unsigned n_pairs, h
   if ((unsigned long long)n_pairs * a.frames_per_launch * a.channels >= (1ull << 26)) return hipErrorInvalidValue;
   FrontendArgs args = a;
   args.fpl_magic = (unsigned)(((1ull << 32) + a.frames_per_launch - 1) / a.frames_per_launch);
+  if (a.frames_per_launch > 1) {
+    // mulhi(t, magic) == t / d for every t of this grid?  (magic d - 2^32) t < 2^32 decides
+    const unsigned long long err = (unsigned long long)args.fpl_magic * a.frames_per_launch - (1ull << 32);
+    const unsigned long long t_max = (unsigned long long)n_pairs * a.frames_per_launch - 1;
+    if (err && t_max >= ((1ull << 32) + err - 1) / err) return hipErrorInvalidValue;
+  }
   const size_t lds = kLdsDoubles * sizeof(double);
   if (bands == 109)
     hipLaunchKernelGGL(frontend_kernel<109>, dim3(grid), dim3(128), lds, stream, args);

@@ -25,8 +25,8 @@ struct FrontendArgs {
   int channels;
   unsigned frame0;              // first frame of this launch
   unsigned frames_per_launch;
-  unsigned fpl_magic;           // ceil(2^32 / frames_per_launch): x / frames_per_launch = mulhi(x, magic) for x < 2^26
-                                // (filled in by launch_frontend)
+  unsigned fpl_magic;           // ceil(2^32 / frames_per_launch): x / frames_per_launch = mulhi(x, magic), exact while
+                                // x (magic d - 2^32) < 2^32 -- launch_frontend fills it in and refuses launches beyond that
   double level_factor;          // fftearmodel.c:312-313
   const CommonTables* common;
   const BandTables* bands;      // FFT model, 109 or 55 bands
@@ -41,6 +41,13 @@ struct FrontendArgs {
   Settings cfg;                 // centre_ehs_window, ehs_dc_before_window
 };
 hipError_t launch_frontend(int bands, const FrontendArgs& a, unsigned n_pairs, hipStream_t stream);
+// Most frames per launch for which the kernel's reciprocal multiplication is exact whatever the divisor:
+// the error term magic d - 2^32 is below d and the dividend below n_pairs d, so n_pairs d^2 <= 2^32 is enough.
+inline unsigned max_frames_per_launch(unsigned n_pairs) {
+  unsigned long long d = 65535;
+  while (d > 1 && (unsigned long long)(n_pairs ? n_pairs : 1) * d * d > (1ull << 32)) d >>= 1;
+  return (unsigned)d;
+}
 
 // ---- pattern back end (time smearing .. MOV accumulation) -------------------
 struct BackendArgs {

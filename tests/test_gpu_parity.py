@@ -276,3 +276,32 @@ def test_run_pair_from_host_memory_equals_the_goldens(gpu):
     empty = np.zeros((0, 2), dtype=np.float32)
     got = gstpeaq_amd.run_pair(gpu.ctx(), 0, empty, empty)
     assert got["frames"] == 0 and np.isnan(got["odg"])
+
+
+def test_half_hour_mono_pair_is_cut_into_exact_launches(gpu):
+    """A long mono file is ONE pair with tens of thousands of frames.  The front end takes a work item apart
+    with a 32-bit reciprocal of the frames per launch (peaq_frontend.hip `decode`), exact only up to
+    max_frames_per_launch(): peaq_run_pair must cut the stream there.  70 000 frames alone == the same pair
+    beside a second one (which forces 64-frame launches), bit for bit, and its last frame is a real one."""
+    import torch
+    import gstpeaq_amd
+    n = 70000 * 1024 + 1024
+    frames = gstpeaq_amd.load_library().peaq_frame_count(n, n, 0)     # 70 000 whole frames + the flush frame
+    assert frames == 70001
+    r1, t1 = synth_np.pair(21, 1, 480000)
+    reps = -(-n // len(r1))
+    ref = np.tile(r1, (reps, 1))[:n].copy()
+    test = np.tile(t1, (reps, 1))[:n].copy()
+    test[-3000:] *= 0.5                                 # the tail differs: a dropped last frame would show
+    alone = gstpeaq_amd.run_pair(gpu.ctx(), 0, ref, test)
+    assert alone["frames"] == frames
+    d_ref = torch.from_numpy(np.stack([ref, ref])).cuda()
+    d_test = torch.from_numpy(np.stack([test, ref])).cuda()
+    both = gstpeaq_amd.batch_run(gpu.ctx(), 0, d_ref, d_test)
+    assert both[0]["frames"] == frames
+    np.testing.assert_array_equal(alone["movs"], both[0]["movs"])
+    assert alone["odg"] == both[0]["odg"] and alone["totalsnr"] == both[0]["totalsnr"]
+    # and the stage entry point beyond one launch: the record of the very last frame is written
+    recs = gstpeaq_amd.debug_frontend(gpu.ctx(), 109, torch.from_numpy(ref[: 66000 * 1024 + 1024]).cuda(),
+                                      torch.from_numpy(test[: 66000 * 1024 + 1024]).cuda(), 66000)
+    assert recs[-1, 0, :109].min() > 0. and recs[65535, 0, :109].min() > 0. and recs[65536, 0, :109].min() > 0.
