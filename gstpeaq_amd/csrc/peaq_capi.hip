@@ -492,6 +492,7 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
       const int b = chunk & 1;
       ff.block0 = b0;
       ff.blocks_per_launch = nb;
+      ff.launch_idx = chunk;                             // (sessions, broker, stage entry points: one stream, always slot 0)
       ff.prev_blocks = prev;
       ff.first_launch = b0 == 0;
       ff.hp_scratch = rows[b];

@@ -23,6 +23,7 @@
 #include "peaq_device.h"
 #include "peaq_kernels.h"
 #include "peaq_wave.h"
+#include <type_traits>
 
 namespace peaq {
 
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
   }
   HpWalk w{st->hp[0], st->hp[1], st->hp[2], st->hp[3], st->hp[4], st->hp[5]};
   HpWalk fin = w;
+  double peak = 0., peak_fin = 0.;                   // largest |filtered sample| of this signal's blocks
 
   // samples are fetched 16 ahead of their use: the walk itself is a chain of dependent FP64
   // operations, the loads (one cache line per lane) must never be waited for
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
         const int k = k0 + j;
         const float xv = xin[j];
         y[j] = w.step((double)xv * a.level_factor);
+        peak = fmax(peak, fabs(y[j]));
         // gstpeaq.c:1083-1096: FLOAT running sum, tested from i = 5 on
         const float ax = fabsf(xv);
         if (k < 5) {
@@ -165,11 +168,18 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
           (double)above;
     // the wave walks on (with zero input) until its longest signal is done: keep the state as it
     // was after this signal's own last block
-    if (bl + 1 == nb_mine) fin = w;
+    if (bl + 1 == nb_mine) {
+      fin = w;
+      peak_fin = peak;
+    }
   }
   if (nb_mine > 0) {
     st->hp[0] = fin.x1; st->hp[1] = fin.x2; st->hp[2] = fin.y1a; st->hp[3] = fin.y2a; st->hp[4] = fin.y1b;
     st->hp[5] = fin.y2b;
+    const int slot = a.launch_idx % 3;
+    st->peak_slot[slot][0] = peak_fin;
+    st->peak_slot[slot][1] = first ? 0. : st->peak_last;   // the window's head is the previous launch's tail
+    st->peak_last = peak_fin;
   }
 }
 
@@ -225,8 +235,8 @@ struct Window<_Float16> {
   alignas(16) unsigned char hi[kWinHBytes];
   alignas(16) unsigned char lo[kWinHBytes];
   __device__ __forceinline__ void put(int u, double x, double scale) {
-    // (full scale sits at 2^10..2^11: a sample 30 dB beyond it would leave FP16's range -- saturate rather than
-    // let an infinity turn the whole tile into NaN)
+    // (full scale sits at 2^10..2^11; a launch whose filtered signal peaks above 2^15 at that scale runs at a
+    // smaller power of two instead -- fb_bank_body, `xs` -- so the clamp below only ever meets NaN/inf input)
     const float s = fminf(fmaxf((float)(x * scale), -65504.f), 65504.f);
     const _Float16 h = (_Float16)s;
     *reinterpret_cast<_Float16*>(hi + winh_off(u)) = h;
@@ -649,12 +659,12 @@ __device__ unsigned long long g_fb_prof[4 * 16 + 4];
 // instructions at four; the per-wave sums leave as FP64 atomics (ds_add_f32 is 22 x slower, see BankLds).
 template <int W, typename WT>
 __device__ __forceinline__ void spread_up_f32(BankLds<WT>& sh, const double (&re)[10], const double (&im)[10],
-                                              const double (&cu)[10], int lane) {
+                                              const float (&cu)[10], int lane) {
   v2f t[10], c[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
     t[i] = v2f{(float)re[i], (float)im[i]};
-    c[i] = v2f{(float)cu[i], (float)cu[i]};
+    c[i] = v2f{cu[i], cu[i]};
   }
 #pragma unroll
   for (int j = 1; j < kFbBands; ++j) {
@@ -709,6 +719,20 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
   const size_t row_valid = (size_t)kFbRing + (size_t)a.blocks_per_launch * kFbFrame;
   const double* __restrict__ row = a.hp_scratch + (size_t)state_idx * row_len;
   FbSignalState* __restrict__ st = a.fbstate + state_idx;
+  // Scale of the split-FP16 operands: the launch's power of two (full scale at 2^10..2^11, 30 dB of headroom)
+  // unless this signal's window -- this launch and the tail of the previous one, peaks recorded by fb_hp_kernel --
+  // reaches beyond 2^15 there: then the power of two that puts ITS peak into [2^14, 2^15).  Samples far beyond
+  // full scale (float WAV files) are therefore scaled, not saturated; ordinary signals keep the one scale that
+  // makes their quantisation independent of where launches cut the stream.
+  int xk = 0;                                        // the scale is 2^-xk times the launch's (kept as the exponent: one
+  if constexpr (sizeof(WT) == 2) {                   // scalar register over the tile loop instead of two doubles)
+    const int slot = a.launch_idx % 3;
+    const double pk = fmax(st->peak_slot[slot][0], st->peak_slot[slot][1]) * a.hf_xscale;
+    if (pk >= 32768. && pk < __builtin_inf()) xk = __builtin_amdgcn_frexp_exp(pk) - 15;   // pk in [2^(14+xk), 2^(15+xk))
+    xk = __builtin_amdgcn_readfirstlane(xk);
+  }
+#define xs __builtin_amdgcn_ldexp(a.hf_xscale, -xk)
+#define xus __builtin_amdgcn_ldexp(a.hf_xunscale, xk)
 
   // recurrent state -> LDS / registers
   if (tid < kFbBands) {
@@ -763,12 +787,12 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
       if constexpr (sizeof(WT) == 2)                 // beyond the window proper: read by the unused time points 60..63 only
         for (int wdx = kWin + tid; wdx < 32 * kWinHBlocks; wdx += 256) sh.win.put(wdx, 0., 0.);
       const int avail = (int)min((size_t)kWin, row_valid);
-      for (int wdx = tid; wdx < kWin; wdx += 256) sh.win.put(wdx, wdx < avail ? row[wdx] : 0., a.hf_xscale);
+      for (int wdx = tid; wdx < kWin; wdx += 256) sh.win.put(wdx, wdx < avail ? row[wdx] : 0., xs);
     } else {
 #pragma unroll
       for (int q = 0; q < kPre; ++q) {
         const int wdx = kKeep + tid + 256 * q;
-        if (wdx < kWin) sh.win.put(wdx, pre[q], a.hf_xscale);
+        if (wdx < kWin) sh.win.put(wdx, pre[q], xs);
       }
     }
     {
@@ -783,7 +807,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     else if constexpr (sizeof(WT) == 4)
       fir_mfma_f32(sh, fb->mf_re_f, fb->mf_im_f, wv, lane);
     else
-      fir_mfma_h3(sh, fb, a.hf_xunscale, wv, lane);
+      fir_mfma_h3(sh, fb, xus, wv, lane);
     FB_MARK(1);
     __syncthreads();                                                 // A is complete
     FB_MARK(2);
@@ -799,7 +823,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
       // band 0 (= re[0] of wave 0): its tap at delay 1456 reads the NEWEST sample in the reference
       // (the doubled ring buffer makes fb_buf[offset + 1456] alias fb_buf[offset], fbearmodel.c:413-414)
       const int tt = lane < kTileSub ? lane : kTileSub - 1;
-      const double delta = sh.win.get(kFbRing + 32 * tt, a.hf_xunscale) - sh.win.get(32 * tt, a.hf_xunscale);
+      const double delta = sh.win.get(kFbRing + 32 * tt, xus) - sh.win.get(32 * tt, xus);
       re[0] = fma(fb->h_re[1], delta, re[0]);
       im[0] = fma(-fb->h_im[1], delta, im[0]);
       sh.a.re[0][lane] = re[0];                      // band 0 is nobody's spreading target
@@ -828,7 +852,8 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     // the tails of ITS ten sources per target band in registers and then issues ONE LDS atomic
     // per target and part (312 per tile instead of 1560; one column per lane: no contention
     // inside an instruction) ------------------------------------------------------------------------
-    double cuv[10];
+    // (the reduced-precision engine spreads in FP32: it keeps the ten slopes as floats)
+    typename std::conditional<sizeof(WT) == 2, float, double>::type cuv[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       const int b = wave_band(wv, i);
@@ -837,15 +862,16 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
       double cu;
       if constexpr (sizeof(WT) == 2) {
         // reduced-precision engine: the hardware's FP32 log2 / exp2 (1 ulp) on |A|^2 taken apart into exponent and
-        // mantissa in FP64, so that the tiny energies of silent bands do not underflow; the slope filter as an
-        // FP32 scan (with the shipped coefficients it forgets its past within two steps)
+        // mantissa in FP64, so that the tiny energies of silent bands do not underflow
         const double p = re[i] * re[i] + im[i] * im[i];
         const float l2 = (float)__builtin_amdgcn_frexp_exp(p) + __builtin_amdgcn_logf((float)__builtin_amdgcn_frexp_mant(p));
         const float ex = fminf((float)(4. * kLnDist / kLn2), fmaf((float)kC1, l2, (float)(c0[i] * (1. / kLn2))));
         const float dist_s = __builtin_amdgcn_exp2f(p == 0. ? -__builtin_inff() : ex);
-        const float v = wave_prefix_geometric((float)sg * dist_s, (float)kM1, (float)kM2, (float)kM4, (float)kM8,
-                                              (float)kM16, (float)decay_row, lane);
-        cu = (double)fmaf((float)decay, (float)sh.cu[b], v);
+        // The slope filter itself runs in FP64 like the reference's: it is the one recurrence ALONG the stream in
+        // this phase, and in FP32 its rounding depended on where a launch (hence a tile) happened to start -- a
+        // session and the batch path then disagreed in the eighth digit.  Everything per time point stays FP32.
+        const double v = wave_prefix_geometric(sg * (double)dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
+        cu = fma(decay, sh.cu[b], v);
       } else {
         const double dist_s = exp_fast(fmin(4. * kLnDist, c0[i] + kC1 * log_nonneg(re[i] * re[i] + im[i] * im[i])));
         const double v = wave_prefix_geometric(sg * dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
@@ -853,7 +879,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
       }
       const double carry = __shfl(cu, nvs - 1, 64);
       if (lane == 0) sh.cu[b] = carry;                               // only this wave touches cu[b]
-      cuv[i] = cu;
+      cuv[i] = (decltype(cuv[0] + 0))cu;
     }
     FB_MARK(5);
     if constexpr (sizeof(WT) == 2) {
@@ -953,6 +979,8 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     for (int i = 0; i < 10; ++i) st->e0_hist[tid][i] = sh.hist[tid][i];
     st->excitation[tid] = exc;
   }
+#undef xs
+#undef xus
 }
 
 // The kernels proper.  Two workgroups per CU either way (LDS); the default arithmetic's kernel is also held to

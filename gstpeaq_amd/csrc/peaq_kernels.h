@@ -100,6 +100,7 @@ struct FbFrontArgs {
   long long off_ref, off_test;
   int channels;
   unsigned block0, blocks_per_launch;
+  unsigned launch_idx;          // running index of this launch (selects the peak slot, FbSignalState::peak_slot)
   unsigned prev_blocks;         // blocks_per_launch of the previous launch on these rows
   int first_launch;             // no history yet: the filter-bank delay line starts at zero
   double level_factor;          // fbearmodel.c:252-253

@@ -27,7 +27,8 @@ def _streams(n, channels):
 
 def _same(got, exp, where, rtol=1e-12):
     # advanced: the filter bank walks the stream in other tile alignments and adds its partial sums
-    # with LDS atomics, which only moves FP64 rounding
+    # with LDS atomics, which only moves FP64 rounding -- in BOTH arithmetics of the bank (the reduced-precision
+    # engine keeps its one recurrence along the stream, the slope filter, in FP64 for exactly this reason)
     assert got["frames"] == exp["frames"], where
     np.testing.assert_allclose(got["movs"], exp["movs"], rtol=rtol, atol=0, equal_nan=True, err_msg=str(where))
     for k, tol in (("di", 1e3 * rtol), ("odg", 1e3 * rtol), ("totalsnr", 1e-9)):
@@ -57,7 +58,7 @@ def _feed(broker, sid, ref, test, rng, tick_every=None):
 
 @pytest.mark.parametrize("advanced", [False, True], ids=["basic", "advanced"])
 @pytest.mark.parametrize("channels", [1, 2])
-def test_broker_sessions_equal_batch(channels, advanced):
+def test_broker_sessions_equal_batch(channels, advanced, fir_mode):
     import gstpeaq_amd
     n = 37
     streams = _streams(n, channels)
@@ -85,7 +86,7 @@ def test_broker_sessions_equal_batch(channels, advanced):
         if rounds % 2 == 0:
             b.tick()
     for i in range(n):
-        _same(b.results(sids[i]), whole[i], i, rtol=1e-9 if advanced else 1e-12)
+        _same(b.results(sids[i]), whole[i], i, rtol=gpu.tol("chunks") if advanced else 1e-12)
         assert b.results(sids[i])["fb_blocks"] == whole[i]["fb_blocks"]
     st = b.stats()
     assert st["max_active"] > 1 and st["launches"] < sum(w["frames"] for w in whole)   # really batched
@@ -94,7 +95,7 @@ def test_broker_sessions_equal_batch(channels, advanced):
 
 
 @pytest.mark.parametrize("advanced", [False, True], ids=["basic", "advanced"])
-def test_broker_tick_thread_and_slot_reuse(advanced):
+def test_broker_tick_thread_and_slot_reuse(advanced, fir_mode):
     import gstpeaq_amd
     channels = 2
     streams = _streams(12, channels)
@@ -125,7 +126,7 @@ def test_broker_tick_thread_and_slot_reuse(advanced):
     b.stop()
     assert not errors, errors
     for i, got in enumerate(results):
-        _same(got, whole[i], i, rtol=1e-9 if advanced else 1e-12)
+        _same(got, whole[i], i, rtol=gpu.tol("chunks") if advanced else 1e-12)
     assert b.stats()["worker_failed"] == 0
     b.close()
 

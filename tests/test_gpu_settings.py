@@ -1,8 +1,8 @@
 """The engine's run-time version of the reference's settings.h switches (include/peaq_amd.h
 peaq_settings; settings.h:47-97) against the REAL reference compiled with each switch flipped
 (tests/golden/ref_e2e_settings.json, see tests/test_oracle_settings.py): batch path, sessions and the
-broker.  Tolerances as for the default build's goldens: MOVs 1e-7 relative, DI / ODG 1e-7.
-Needs an MI355X (`-m gpu`)."""
+broker.  Tolerances as for the default build's goldens (tests/gpu_common.py TOL, per arithmetic of the
+filter bank; the basic version 1e-7).  Needs an MI355X (`-m gpu`)."""
 import json
 
 import numpy as np
@@ -21,14 +21,16 @@ def _records(golden_dir, advanced):
 
 def _check(got, rec):
     exp = np.array([float(v) for v in rec["movs"]])
+    adv = rec["case"]["advanced"]
+    odg_tol = gpu.tol("odg") if adv else 1e-7
     assert got["frames"] == rec["frames"]
-    np.testing.assert_allclose(got["movs"][: len(exp)], exp, rtol=1e-7, atol=1e-9,
+    np.testing.assert_allclose(got["movs"][: len(exp)], exp, rtol=gpu.tol("movs", adv), atol=1e-9,
                                err_msg=f"{rec['variant']} {rec['case']['name']}")
-    assert abs(got["odg"] - rec["odg"]) <= 1e-7 and abs(got["di"] - rec["di"]) <= 1e-7, (rec["variant"], got, rec)
+    assert abs(got["odg"] - rec["odg"]) <= odg_tol and abs(got["di"] - rec["di"]) <= odg_tol, (rec["variant"], got, rec)
 
 
 @pytest.mark.parametrize("advanced", [0, 1])
-def test_batch_matches_the_reference_built_with_other_settings(golden_dir, advanced):
+def test_batch_matches_the_reference_built_with_other_settings(golden_dir, advanced, fir_mode):
     ctx = gpu.ctx()
     assert ctx.settings() == dict(swap_mod_patts_for_noise_loudness_movs=1, center_ehs_correlation_window=0,
                                   ehs_subtract_dc_before_window=1, use_floor_for_steps_above_threshold=0,
@@ -43,7 +45,7 @@ def test_batch_matches_the_reference_built_with_other_settings(golden_dir, advan
             if rec["odg"] != rec["odg_default"]:
                 ctx.set_settings()
                 dflt = gpu.run_batch([case_defs.make_inputs(case)], advanced, case["channels"])[0]
-                assert abs(dflt["odg"] - rec["odg_default"]) <= 1e-7
+                assert abs(dflt["odg"] - rec["odg_default"]) <= (gpu.tol("odg") if advanced else 1e-7)
     finally:
         ctx.set_settings()
 
