@@ -127,9 +127,13 @@ wav_read (const char *path, wav_t * w)
 }
 
 /* ---- sample-rate conversion to 48 kHz (stands in for audioresample, peaq.c:154-209) ----
- * y[m] = sum_n x[n] h(m / 48000 - n / rate), h = Kaiser-windowed sinc with the cutoff below the
- * lower of the two Nyquist frequencies, evaluated directly in double precision (a file is
- * converted once; no polyphase table needed). */
+ * y[m] = sum_n x[n] h(t_m - n), t_m = m rate / 48000 - 1/8, h = Kaiser-windowed sinc.
+ * The parameters are those of the reference's chain as it runs here -- `audioresample` of GStreamer 1.14 at its
+ * default quality, measured through its impulse response (tools/make_golden.py resampled; the fit leaves 5e-5
+ * of the peak): cutoff 0.94 of the input's Nyquist frequency and 64 taps when the rate goes up, 0.921 of the
+ * output's and 64 rate / 48000 taps (rounded up to a multiple of 8) when it goes down, Kaiser beta 8.4-8.5 (85 dB),
+ * and a delay of one eighth of an INPUT sample; the last output sample is the last one whose position does not
+ * pass the last input sample.  Rational ratios (44.1 kHz: 160 / 147) run from a polyphase table. */
 static double
 bessel_i0 (double x)
 {
@@ -144,41 +148,92 @@ bessel_i0 (double x)
   return sum;
 }
 
+typedef struct
+{
+  double fc, half, beta, i0b;
+} rs_kernel;
+
+static double
+rs_tap (const rs_kernel * k, double d)
+{                               /* h(d), d in input samples */
+  const double u = d / k->half, arg = 2. * M_PI * k->fc * d;
+  if (fabs (u) > 1.)
+    return 0.;
+  return 2. * k->fc * (fabs (arg) < 1e-12 ? 1. : sin (arg) / arg) * bessel_i0 (k->beta * sqrt (1. - u * u)) / k->i0b;
+}
+
+static unsigned long
+gcd_ul (unsigned long a, unsigned long b)
+{
+  while (b) {
+    const unsigned long t = a % b;
+    a = b;
+    b = t;
+  }
+  return a;
+}
+
 static int
 resample_to_48k (wav_t * w)
 {
   const double ratio = 48000. / w->rate;                        /* output samples per input sample */
-  const double fc = 0.96 * 0.5 * (ratio < 1. ? ratio : 1.);     /* cutoff in cycles per INPUT sample */
-  const int zc = 64;                                            /* zero crossings on each side */
-  const double half = zc / (2. * fc);                           /* half width of the kernel in input samples */
-  const double beta = 12.9846;                                  /* Kaiser: -125 dB stop band */
-  const double i0b = bessel_i0 (beta);
-  const size_t out_frames = (size_t) floor ((double) w->frames * ratio);
+  const double delay = 0.125;                                   /* input samples */
+  rs_kernel k;
+  const unsigned long g = gcd_ul (48000ul, (unsigned long) w->rate);
+  const unsigned long L = 48000ul / g, M = (unsigned long) w->rate / g;   /* t_m = m M / L - delay */
+  const size_t out_frames = w->frames ? (size_t) floor ((double) (w->frames - 1) * ratio) + 1 : 0;
   float *out = malloc ((out_frames ? out_frames : 1) * w->channels * sizeof (float));
+  double *table = NULL;
+  long K, j;
   size_t m;
   int c;
   if (!out)
     return -1;
+  if (ratio >= 1.) {
+    k.fc = 0.94 * 0.5;
+    k.half = 32.15;
+    k.beta = 8.49;
+  } else {
+    k.fc = 0.921 * 0.5 * ratio;
+    k.half = 4. * ceil (64. / ratio / 8.);
+    k.beta = 8.41;
+  }
+  k.i0b = bessel_i0 (k.beta);
+  K = (long) ceil (k.half) + 1;                                 /* taps n = floor(t) - K + 1 .. floor(t) + K */
+  if (L <= 4096) {                                              /* phase p = (m M) mod L: d = frac(t) + K - 1 - j */
+    unsigned long p;
+    table = malloc ((size_t) L * 2 * K * sizeof (double));
+    if (!table) {
+      free (out);
+      return -1;
+    }
+    for (p = 0; p < L; p++) {
+      /* t = q + p / L - delay with an integer q: floor and fraction of p / L - delay */
+      const double tf = (double) p / (double) L - delay, fl = floor (tf), fr = tf - fl;
+      for (j = 0; j < 2 * K; j++)
+        table[p * 2 * K + j] = rs_tap (&k, fr + (double) (K - 1 - j));
+    }
+  }
   for (m = 0; m < out_frames; m++) {
-    const double t = (double) m / ratio;                        /* position in input samples */
-    long n0 = (long) ceil (t - half), n1 = (long) floor (t + half), n;
+    const unsigned long long mm = (unsigned long long) m * M;
+    const unsigned long p = (unsigned long) (mm % L);
+    const double tf = (double) p / (double) L - delay, fl = floor (tf);
+    const long n_first = (long) (mm / L) + (long) fl - K + 1;    /* floor(t) - K + 1 */
+    const double fr = tf - fl;
     double acc[2] = { 0., 0. };
-    if (n0 < 0)
-      n0 = 0;
-    if (n1 > (long) w->frames - 1)
-      n1 = (long) w->frames - 1;
-    for (n = n0; n <= n1; n++) {
-      const double d = t - (double) n, u = d / half;
-      const double arg = 2. * M_PI * fc * d;
-      const double snc = fabs (arg) < 1e-12 ? 1. : sin (arg) / arg;
-      const double win = bessel_i0 (beta * sqrt (1. - u * u > 0. ? 1. - u * u : 0.)) / i0b;
-      const double h = 2. * fc * snc * win;
+    for (j = 0; j < 2 * K; j++) {
+      const long n = n_first + j;
+      double h;
+      if (n < 0 || n >= (long) w->frames)
+        continue;
+      h = table ? table[p * 2 * K + j] : rs_tap (&k, fr + (double) (K - 1 - j));
       for (c = 0; c < w->channels; c++)
         acc[c] += h * w->samples[(size_t) n * w->channels + c];
     }
     for (c = 0; c < w->channels; c++)
       out[m * w->channels + c] = (float) acc[c];
   }
+  free (table);
   free (w->samples);
   w->samples = out;
   w->frames = out_frames;
@@ -259,6 +314,25 @@ main (int argc, char **argv)
     free (m->samples);
     m->samples = st;
     m->channels = 2;
+  }
+  if (getenv ("PEAQ_AMD_CLI_DUMP")) {
+    /* test hook (tests/test_cli_resampler.py, runs without a GPU): what would be handed to the engine, as raw
+     * interleaved F32 in <value>.ref.f32 / <value>.test.f32 -- reader, rate conversion and up-mix on their own */
+    const wav_t *w[2] = { &ref, &test };
+    const char *suffix[2] = { ".ref.f32", ".test.f32" };
+    for (i = 0; i < 2; i++) {
+      char path[4096];
+      FILE *f;
+      snprintf (path, sizeof path, "%s%s", getenv ("PEAQ_AMD_CLI_DUMP"), suffix[i]);
+      f = fopen (path, "wb");
+      if (!f || fwrite (w[i]->samples, sizeof (float), w[i]->frames * w[i]->channels, f) != w[i]->frames * w[i]->channels) {
+        fprintf (stderr, "Error: cannot write %s\n", path);
+        return 2;
+      }
+      fclose (f);
+    }
+    printf ("dumped %zu and %zu frames, %d channels\n", ref.frames, test.frames, ref.channels);
+    return 0;
   }
   if (peaq_ctx_create (getenv ("PEAQ_AMD_DEVICE") ? atoi (getenv ("PEAQ_AMD_DEVICE")) : 0, &ctx) != PEAQ_OK) {
     printf ("Error: peaq engine could not be instantiated - %s\n", peaq_last_error ());

@@ -11,6 +11,8 @@ def make_inputs(case):
     """-> (ref, test): float32 [n, channels] arrays (lengths may differ)."""
     kind = case["kind"]
     ch = case.get("channels", 1)
+    if kind == "raw":                                  # the caller's own samples on both pads
+        return case["_x"], case["_x"].copy()
     if kind == "synth":
         ref, test = synth_np.pair(case["seed"], ch, case["n"])
         if case.get("identical"):
@@ -73,6 +75,17 @@ def level_cases():
         for level, seed in ((60.0, 3), (75.5, 4), (105.0, 5), (130.0, 6)):
             cases.append(dict(name=f"synth_s{seed}_L{level:g}", kind="synth", seed=seed, channels=2, n=96000,
                               level=level, advanced=adv))
+    return cases
+
+
+def resampled_cases():
+    """pairs at other sampling rates than 48 kHz, which the reference's CLI takes through audioresample
+    (peaq.c:154-209): the samples of a seeded pair, declared to run at `rate`"""
+    cases = []
+    for adv in (0, 1):
+        for rate, channels, seed, seconds in ((44100, 2, 31, 4), (44100, 1, 32, 4), (32000, 2, 33, 4), (96000, 1, 34, 3)):
+            cases.append(dict(name=f"synth_s{seed}_{rate}Hz", kind="synth", seed=seed, channels=channels,
+                              n=rate * seconds, rate=rate, advanced=adv))
     return cases
 
 

@@ -12,6 +12,9 @@ not exist on the GPU box, the committed fixtures travel instead.
   tests/golden/ref_e2e_level.json     the same for other playback levels      (python tools/make_golden.py levels)
   tests/golden/ref_e2e_settings.json  the same for the reference built with each settings.h switch flipped
                                       (oracle/Makefile ref_variants)          (python tools/make_golden.py settings)
+  tests/golden/ref_e2e_resampled.json pairs at 44.1 / 32 / 96 kHz through the chain of the reference's CLI,
+                                      rawaudioparse ! audioconvert ! audioresample ! peaq (peaq.c:154-209), and the
+                                      measured prototype filter of that audioresample  (python tools/make_golden.py resampled)
 """
 import json
 import os
@@ -139,6 +142,87 @@ def e2e_settings():
     (GOLD / "ref_e2e_settings.json").write_text(json.dumps(results, indent=0))
 
 
+GST_ENV = dict(os.environ, PATH="/opt/conda/bin:" + os.environ["PATH"],
+               GST_PLUGIN_SYSTEM_PATH="/opt/conda/lib/gstreamer-1.0",
+               GST_PLUGIN_SCANNER="/opt/conda/libexec/gstreamer-1.0/gst-plugin-scanner",
+               GST_REGISTRY="/tmp/peaq_ref_harness_registry.bin")
+
+
+def _gst_resample(src, dst, rate, channels):
+    """the front half of the reference CLI's chain on a raw F32 file (wavparse is not in this image; it only
+    unpacks the RIFF container)"""
+    subprocess.run(["gst-launch-1.0", "-q", "filesrc", f"location={src}", "!", "rawaudioparse", "format=pcm",
+                    "pcm-format=f32le", f"sample-rate={rate}", f"num-channels={channels}", "!", "audioconvert", "!",
+                    "audioresample", "!", "audio/x-raw,format=F32LE,rate=48000", "!", "filesink", f"location={dst}"],
+                   check=True, env=GST_ENV)
+
+
+def e2e_resampled():
+    """tests/golden/ref_e2e_resampled.json.  Per case the reference's results on the stream its own chain
+    delivers: audioresample's output is written to a file and handed to the element by the harness (the element
+    does not care how its buffers are cut), and the ODG is cross-checked against the element sitting directly
+    behind audioresample in one gst-launch pipeline.  Also the impulse response of that audioresample (its
+    default quality), fitted with a Kaiser-windowed sinc: the parameters gstpeaq_amd/cli/peaq.c runs with."""
+    subprocess.run(["make", "-C", str(ROOT / "oracle"), "ref"], check=True)
+    results = []
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        for case in case_defs.resampled_cases():
+            ref, test = case_defs.make_inputs(case)
+            for name, x in (("r", ref), ("t", test)):
+                x.astype("<f4").tofile(td / f"{name}.f32")
+                _gst_resample(td / f"{name}.f32", td / f"{name}48.f32", case["rate"], case["channels"])
+            r = run_harness("pair", case["advanced"], case["channels"], td / "r48.f32", td / "t48.f32")
+            chain = []
+            for name in "rt":
+                chain += ["filesrc", f"location={td / (name + '.f32')}", "!", "rawaudioparse", "format=pcm", "pcm-format=f32le",
+                          f"sample-rate={case['rate']}", f"num-channels={case['channels']}", "!", "audioconvert", "!",
+                          "audioresample", "!", "peaq." + ("ref" if name == "r" else "test")]
+            out = subprocess.run(["gst-launch-1.0", "-q", f"--gst-plugin-load={ROOT / 'oracle' / '_ref' / 'libgstpeaq.so'}",
+                                  *chain, "peaq", "name=peaq", f"advanced={'true' if case['advanced'] else 'false'}"],
+                                 check=True, capture_output=True, text=True, env=GST_ENV).stdout
+            printed = [line for line in out.splitlines() if line.startswith("Objective Difference Grade")][-1].split()[-1]
+            assert printed == "%.3f" % float(r["odg"][0]), (case["name"], printed, r["odg"])
+            n48 = (td / "r48.f32").stat().st_size // (4 * case["channels"])
+            results.append(dict(case=case, frames=r["frames"], fb_frames=r["fb_frames"], samples_48k=n48, movs=r["movs"],
+                                di=r["di"][0], odg=r["odg"][0]))
+            print(f"{case['name']:22s} adv={case['advanced']} 48 kHz samples {n48} odg={r['odg'][0]}")
+        proto = {}
+        from scipy.optimize import least_squares
+        from scipy.special import i0
+        for rate in (44100, 32000, 96000):
+            ratio, K = 48000 / rate, 160
+            x = np.zeros((2000 * K + 4000, 1), np.float32)
+            pos = [1000 + 2001 * k for k in range(K)]
+            x[pos, 0] = 1.0
+            x.astype("<f4").tofile(td / "i.f32")
+            _gst_resample(td / "i.f32", td / "i48.f32", rate, 1)
+            y = np.fromfile(td / "i48.f32", dtype="<f4").astype(np.float64)
+            span = int(70 * max(ratio, 1 / ratio)) + 70
+            tau, val = [], []
+            for p in pos:
+                m = np.arange(int(round(p * ratio)) - span, int(round(p * ratio)) + span + 1)
+                tau.append(m / ratio - 0.125 - p)        # audioresample delays by 1/8 input sample (see the fit's residual)
+                val.append(y[m])
+            tau, val = np.concatenate(tau), np.concatenate(val)
+
+            def model(p, tau=tau):
+                cut, half, beta = p
+                fc = cut * 0.5 * min(ratio, 1.)
+                u = tau / half
+                win = np.where(np.abs(u) <= 1, i0(beta * np.sqrt(np.maximum(1 - u * u, 0))) / i0(beta), 0.)
+                return 2 * fc * np.sinc(2 * fc * tau) * win
+            fit = min((least_squares(lambda p: model(p) - val, [0.94, h0, 8.4]) for h0 in (24., 32., 48., 64.)),
+                      key=lambda r: r.cost)
+            proto[str(rate)] = dict(cutoff_of_lower_nyquist=fit.x[0], half_width_input_samples=fit.x[1], kaiser_beta=fit.x[2],
+                                    delay_input_samples=0.125, max_residual=float(np.abs(model(fit.x) - val).max()),
+                                    peak=float(val.max()))
+            print("audioresample prototype at", rate, proto[str(rate)])
+    (GOLD / "ref_e2e_resampled.json").write_text(json.dumps(dict(
+        chain="rawaudioparse ! audioconvert ! audioresample ! peaq (GStreamer 1.14.0, audioresample at its default quality)",
+        audioresample_prototype=proto, records=results), indent=0))
+
+
 def stages():
     arrays = {}
     with tempfile.TemporaryDirectory() as td:
@@ -170,6 +254,9 @@ def main():
     if sys.argv[1:] == ["settings"]:                 # only the settings.h variants
         GOLD.mkdir(parents=True, exist_ok=True)
         e2e_settings()
+        return
+    if sys.argv[1:] == ["resampled"]:                # only the other sampling rates
+        e2e_resampled()
         return
     subprocess.run(["make", "-C", str(ROOT / "oracle"), "ref"], check=True)
     GOLD.mkdir(parents=True, exist_ok=True)
