@@ -40,7 +40,11 @@ _LIB = None
 
 class _BrokerStats(C.Structure):
     _fields_ = [("ticks", C.c_uint64), ("launches", C.c_uint64), ("frames", C.c_uint64),
-                ("max_active", C.c_uint32), ("worker_failed", C.c_uint32)]
+                ("max_active", C.c_uint32), ("worker_failed", C.c_uint32),
+                ("tick_host_us_max", C.c_double), ("tick_host_us_p99", C.c_double), ("tick_host_us_mean", C.c_double),
+                ("tick_device_us_max", C.c_double), ("tick_device_us_p99", C.c_double), ("tick_device_us_mean", C.c_double),
+                ("latency_us_max", C.c_double), ("latency_us_p99", C.c_double), ("latency_us_mean", C.c_double),
+                ("latency_samples", C.c_uint64)]
 
 
 def library_path():

@@ -1331,6 +1331,34 @@ struct BrokerSlot {
   uint64_t fft_pos[2] = {0, 0};
   uint64_t fb_pos[2] = {0, 0};
   uint32_t frames_done = 0, blocks_done = 0, fb_prev_blocks = 0;
+  double t_ready_us = -1.;          // when the oldest not yet launched frame / block became whole (-1: none waiting)
+};
+
+// microseconds on a monotonic clock (latency bookkeeping of the broker)
+static double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// running maximum + histogram with eight buckets per octave (1 us .. 2^26 us)
+struct UsHistogram {
+  uint64_t n = 0, bucket[8 * 27] = {};
+  double max = 0., sum = 0.;
+  void add(double us) {
+    ++n;
+    sum += us;
+    max = std::max(max, us);
+    const int i = us <= 1. ? 0 : std::min<int>(8 * 27 - 1, (int)(8. * std::log2(us)));
+    ++bucket[i];
+  }
+  double quantile(double q) const {                  // upper edge of the bucket that holds it
+    if (!n) return 0.;
+    uint64_t need = (uint64_t)std::ceil(q * (double)n), seen = 0;
+    for (int i = 0; i < 8 * 27; ++i) {
+      seen += bucket[i];
+      if (seen >= need) return std::min(max, std::exp2((i + 1) / 8.));
+    }
+    return max;
+  }
 };
 
 // staging of one kind of unit (FFT frames or filter-bank blocks): pinned host + device buffers
@@ -1465,6 +1493,12 @@ struct peaq_broker {
   std::condition_variable tick_cv;
   uint64_t n_ticks = 0, n_launches = 0, n_frames = 0;
   uint32_t max_active = 0;
+  // timing (peaq_broker_stats_t): the device part of a tick is known when the next tick (or a read-out) has
+  // waited for it, so the waits of its sessions are parked until then
+  hipEvent_t t_begin = nullptr, t_end = nullptr;
+  UsHistogram h_host, h_device, h_latency;
+  std::vector<float> parked_wait_us;
+  double parked_host_us = 0.;
   std::vector<BrokerJob> jobs;      // this tick's staging work
   std::unique_ptr<StagePool> stagers;
 };
@@ -1480,6 +1514,18 @@ static void broker_stage_copy(const peaq_broker* b, const BrokerSlot& sl, const 
   }
 }
 
+// the previous tick's device work is complete: its device time is known now, and with it the latency of the
+// sessions it served (wait for the tick + the tick's host part + its device part)
+static void broker_settle_timing(peaq_broker* b) {
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, b->t_begin, b->t_end) != hipSuccess) ms = 0.f;
+  const double dev_us = 1e3 * ms;
+  b->h_device.add(dev_us);
+  b->h_host.add(b->parked_host_us);
+  for (float w : b->parked_wait_us) b->h_latency.add((double)w + b->parked_host_us + dev_us);
+  b->parked_wait_us.clear();
+}
+
 static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
   peaq_ctx* c = b->ctx;
   if (n_active_out) *n_active_out = 0;
@@ -1487,7 +1533,9 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
   if (b->staged_pending) {
     HIP_TRY(hipEventSynchronize(b->staged));
     b->staged_pending = false;
+    broker_settle_timing(b);
   }
+  const double t_tick = now_us();
   const size_t S = (size_t)b->max_sessions;
   uint32_t* m_nref = b->h_meta;
   uint32_t* m_ntest = b->h_meta + S;
@@ -1580,7 +1628,14 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
     }
     if (sl.flush_requested && sl.fft_flushed && (!b->advanced || sl.fb_flushed))
       sl.flush_requested = sl.fft_flushed = sl.fb_flushed = false;
-    if (job.fft || job.fb) b->jobs.push_back(job);
+    if (job.fft || job.fb) {
+      b->jobs.push_back(job);
+      if (sl.t_ready_us >= 0.) b->parked_wait_us.push_back((float)(t_tick - sl.t_ready_us));
+      // more whole units left behind (the per-tick cap)?  They have been waiting since now at the latest.
+      const uint64_t av = std::min(sl.pad[0].total - sl.fft_pos[0], sl.pad[1].total - sl.fft_pos[1]);
+      const uint64_t avb = b->advanced ? std::min(sl.pad[0].total - sl.fb_pos[0], sl.pad[1].total - sl.fb_pos[1]) : 0;
+      sl.t_ready_us = (av >= (uint64_t)kFrame || avb >= (uint64_t)kFbFrame || sl.flush_requested) ? t_tick : -1.;
+    }
   }
   ++b->n_ticks;
   if (!active && !fb_active) return PEAQ_OK;
@@ -1598,6 +1653,7 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
       sl.pad[p].drop_until(keep_from, b->channels);
     }
   });
+  HIP_TRY(hipEventRecord(b->t_begin, b->stream));
   HIP_TRY(hipMemcpyAsync(b->d_meta.p, b->h_meta, 7 * S * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
   const uint32_t* d_meta = b->d_meta.as<uint32_t>();
   if (active) {
@@ -1670,8 +1726,10 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
     fbk.windows = ff.windows;
     HIP_TRY(launch_fb_backend(fbk, fb_active, b->stream));
   }
+  HIP_TRY(hipEventRecord(b->t_end, b->stream));
   HIP_TRY(hipEventRecord(b->staged, b->stream));
   b->staged_pending = true;
+  b->parked_host_us = now_us() - t_tick;
   ++b->n_launches;
   b->n_frames += frames;
   b->max_active = std::max(b->max_active, std::max(active, fb_active));
@@ -1737,6 +1795,8 @@ extern "C" int peaq_broker_create(peaq_ctx* c, int advanced, int channels, doubl
     HIP_TRY(b->result.reserve(sizeof(ResultRecord)));
     HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&b->staged, hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&b->t_begin));
+    HIP_TRY(hipEventCreate(&b->t_end));
     HIP_TRY(launch_state_init(b->state.as<PairState>(), b->advanced, max_sessions, b->stream));
     if (b->advanced) {
       r = b->fbs.alloc(S, kBrokerFbStageSamples, channels);
@@ -1784,6 +1844,8 @@ extern "C" void peaq_broker_destroy(peaq_broker* b) {
   b->hp_rows.release();
   b->result.release();
   if (b->staged) (void)hipEventDestroy(b->staged);
+  if (b->t_begin) (void)hipEventDestroy(b->t_begin);
+  if (b->t_end) (void)hipEventDestroy(b->t_end);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   for (BrokerSlot* s : b->slots) delete s;
   delete b;
@@ -1807,6 +1869,7 @@ extern "C" int peaq_broker_open(peaq_broker* b, int* session_id) {
     sl.pad[1] = PadFifo();
     sl.fft_pos[0] = sl.fft_pos[1] = sl.fb_pos[0] = sl.fb_pos[1] = 0;
     sl.frames_done = sl.blocks_done = sl.fb_prev_blocks = 0;
+    sl.t_ready_us = -1.;
     *session_id = sid;
     return PEAQ_OK;
   }
@@ -1854,6 +1917,11 @@ extern "C" int peaq_broker_push(peaq_broker* b, int session_id, int pad, const f
       return fail(PEAQ_ERR_NOMEM, "out of host memory");
     }
     f.total += n;
+    if (sl->t_ready_us < 0.) {
+      const uint64_t av = std::min(sl->pad[0].total - sl->fft_pos[0], sl->pad[1].total - sl->fft_pos[1]);
+      const uint64_t avb = b->advanced ? std::min(sl->pad[0].total - sl->fb_pos[0], sl->pad[1].total - sl->fb_pos[1]) : 0;
+      if (av >= (uint64_t)kFrame || avb >= (uint64_t)kFbFrame) sl->t_ready_us = now_us();
+    }
   }
   // back-pressure (the reference processes inside pad_chain, so its caller can never run ahead):
   // wait for the tick thread, or tick right here when there is none
@@ -1879,6 +1947,7 @@ extern "C" int peaq_broker_flush(peaq_broker* b, int session_id) {
   if (!sl->open) return fail(PEAQ_ERR_STATE, "peaq_broker_flush: session is not open");
   sl->flush_requested = true;
   sl->fft_flushed = sl->fb_flushed = false;
+  if (sl->t_ready_us < 0.) sl->t_ready_us = now_us();
   return PEAQ_OK;
 }
 
@@ -1953,5 +2022,21 @@ extern "C" int peaq_broker_stats(peaq_broker* b, peaq_broker_stats_t* out) {
   out->frames = b->n_frames;
   out->max_active = b->max_active;
   out->worker_failed = b->failed.load() ? 1 : 0;
+  if (b->staged_pending && !b->failed.load()) {        // settle the last tick's timing
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(hipEventSynchronize(b->staged));
+    b->staged_pending = false;
+    broker_settle_timing(b);
+  }
+  out->tick_host_us_max = b->h_host.max;
+  out->tick_host_us_p99 = b->h_host.quantile(0.99);
+  out->tick_host_us_mean = b->h_host.n ? b->h_host.sum / (double)b->h_host.n : 0.;
+  out->tick_device_us_mean = b->h_device.n ? b->h_device.sum / (double)b->h_device.n : 0.;
+  out->tick_device_us_max = b->h_device.max;
+  out->tick_device_us_p99 = b->h_device.quantile(0.99);
+  out->latency_us_max = b->h_latency.max;
+  out->latency_us_p99 = b->h_latency.quantile(0.99);
+  out->latency_us_mean = b->h_latency.n ? b->h_latency.sum / (double)b->h_latency.n : 0.;
+  out->latency_samples = b->h_latency.n;
   return PEAQ_OK;
 }

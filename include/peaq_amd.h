@@ -167,6 +167,15 @@ typedef struct peaq_broker_stats_t {
   uint64_t frames;       /* FFT frames (per session, not per channel) run    */
   uint32_t max_active;   /* most sessions served by a single launch          */
   uint32_t worker_failed;/* the tick thread stopped on a device error        */
+  /* Timing, in microseconds, over the ticks that launched device work (max, and the 99th percentile from a
+   * histogram with 9 % resolution).  A session's LATENCY is the time from "a whole frame (block) of both pads
+   * sits in its FIFO" (or its flush was requested) to "the device work of the tick that took it is complete",
+   * i.e. wait for the next tick + that tick's host part + its device part: what the reference does inside
+   * pad_chain (gstpeaq.c:614-661) the broker does at most one tick period later. */
+  double   tick_host_us_max, tick_host_us_p99, tick_host_us_mean;        /* scan + staging copies + enqueue           */
+  double   tick_device_us_max, tick_device_us_p99, tick_device_us_mean;  /* copies and kernels of one tick on the GPU */
+  double   latency_us_max, latency_us_p99, latency_us_mean;
+  uint64_t latency_samples;                         /* (session, tick) pairs behind the latency figures */
 } peaq_broker_stats_t;
 int  peaq_broker_create  (peaq_ctx *ctx, int advanced, int channels, double playback_level_db,
                           int max_sessions, peaq_broker **out);

@@ -8,13 +8,16 @@
 // own tick thread batches whatever became ready.  At the end every session is
 // flushed (do_flush, gstpeaq.c:716-745) and its result compared with the batch
 // path run on the SAME seeded pairs: bit-equal in the basic version; in the
-// advanced one 1e-9 relative with the all-FP64 engine (LDS-atomic summation
-// order) and 5e-6 with the default one, whose FP32 slope filter
-// rounds differently when a stream is cut into other launches (48 blocks per
-// tick here, 840 per launch in the batch path).
+// advanced one 1e-9 relative in either arithmetic of the filter bank (LDS-atomic
+// summation order; a stream is cut into 48 blocks per tick here,
+// 840 per launch in the batch path).
 //
 //   broker_feeder [--sessions N] [--seconds S] [--threads T] [--chunk SAMPLES]
 //                 [--channels C] [--advanced] [--period-us P] [--seed0 K] [--ragged]
+//                 [--realtime]
+// --realtime: every session delivers --chunk samples per pad every chunk / 48000 s (1024: one
+// frame-pair per 21.3 ms, the pace of a live pipeline) instead of as fast as the feeders can
+// push; the latency figures of peaq_broker_stats_t are what this mode is for.
 // Prints one JSON object; exit status 0 = all sessions match the batch results.
 //
 // Build: make -C tools   (hipcc; links ../gstpeaq_amd/libpeaq_amd.so)
@@ -58,7 +61,7 @@ static bool same_value(double a, double b, double rtol) {
 }
 
 int main(int argc, char** argv) {
-  int sessions = 1024, threads = 16, channels = 2, advanced = 0, ragged = 0;
+  int sessions = 1024, threads = 16, channels = 2, advanced = 0, ragged = 0, realtime = 0;
   double seconds = 2.0;
   unsigned chunk = 4096, period_us = 1000, seed0 = 1;
   for (int i = 1; i < argc; ++i) {
@@ -72,6 +75,7 @@ int main(int argc, char** argv) {
     else if (arg("--seed0")) seed0 = (unsigned)std::strtoul(argv[++i], nullptr, 0);
     else if (!std::strcmp(argv[i], "--advanced")) advanced = 1;
     else if (!std::strcmp(argv[i], "--ragged")) ragged = 1;
+    else if (!std::strcmp(argv[i], "--realtime")) realtime = 1;
     else {
       std::fprintf(stderr, "unknown argument %s (see the header of tools/broker_feeder.cpp)\n", argv[i]);
       return 1;
@@ -120,8 +124,17 @@ int main(int argc, char** argv) {
         for (int s = t; s < sessions; s += threads) mine.push_back(s);
         std::vector<uint32_t> pos(mine.size(), 0);
         bool more = true;
+        unsigned round = 0;
+        // --realtime: round r of this thread is due at t0 + r chunk / 48000 (+ a per-thread offset, so that the
+        // sessions do not all become ready in the same instant: live pipelines are not phase locked)
+        const double round_s = (double)chunk / 48000., phase_s = round_s * t / threads;
         while (more) {
           more = false;
+          if (realtime) {
+            const double due = t0 + phase_s + round * round_s, wait = due - now_s();
+            if (wait > 0) std::this_thread::sleep_for(std::chrono::duration<double>(wait));
+            ++round;
+          }
           for (size_t k = 0; k < mine.size(); ++k) {
             const int s = mine[k];
             if (pos[k] >= ns) continue;
@@ -182,10 +195,14 @@ int main(int argc, char** argv) {
       "\"chunk\": %u, \"ragged\": %d, \"period_us\": %u, \"frame_pairs\": %.0f, \"feed_s\": %.4f, \"total_s\": %.4f, "
       "\"frame_pairs_per_s\": %.1f, \"x_realtime\": %.1f, \"ticks\": %llu, \"launches\": %llu, "
       "\"max_active\": %u, \"worker_failed\": %u, \"feed_errors\": %d, \"mismatches\": %d, \"odg_nan\": %d, "
-      "\"max_abs_dodg_vs_batch\": %.3g}\n",
+      "\"max_abs_dodg_vs_batch\": %.3g, \"realtime\": %d, \"tick_host_us_max\": %.1f, \"tick_host_us_p99\": %.1f, \"tick_host_us_mean\": %.1f, "
+      "\"tick_device_us_max\": %.1f, \"tick_device_us_p99\": %.1f, \"tick_device_us_mean\": %.1f, \"latency_us_max\": %.1f, \"latency_us_p99\": %.1f, "
+      "\"latency_us_mean\": %.1f, \"latency_samples\": %llu}\n",
       sessions, advanced, channels, seconds, threads, chunk, ragged, period_us, frames, t_fed - t0, t1 - t0,
       frames / (t1 - t0), sessions * seconds / (t1 - t0), (unsigned long long)st.ticks,
       (unsigned long long)st.launches, st.max_active, st.worker_failed, feed_errors.load(), mismatches, nan_odg,
-      max_dodg);
+      max_dodg, realtime, st.tick_host_us_max, st.tick_host_us_p99, st.tick_host_us_mean, st.tick_device_us_max, st.tick_device_us_p99,
+      st.tick_device_us_mean,
+      st.latency_us_max, st.latency_us_p99, st.latency_us_mean, (unsigned long long)st.latency_samples);
   return (mismatches || feed_errors.load() || st.worker_failed) ? 3 : 0;
 }
