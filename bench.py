@@ -26,7 +26,10 @@ from the reference's sources; the C oracle if that binary is absent) on one core
 and on all host cores; `odg_max_abs_delta` etc. compare the GPU results with the
 reference's on the pairs the single-core leg ran (the second half of
 BASELINE.json's metric); `advanced` carries configs[2] (advanced model, same
-pairs) with its own roofline (filter bank on the FP64 matrix cores).
+pairs) at the reference's precision -- every stage FP64 -- with the roofline of
+that engine's filter-bank kernel, and the engine's default (reduced-precision
+FIR) as the labelled sub-object `reduced_precision_default`;
+`scaling_reference` is this GPU in the regime every rank of an N > 1 run is in.
 """
 import argparse
 import json
@@ -173,10 +176,22 @@ def result_deltas(gpu_rows, cpu, advanced):
 
 
 # ----------------------------------------------------------------------------------------------
+def source_hash():
+    """sha256 over the kernel sources (gstpeaq_amd/csrc/*): what the counter profiles are valid for"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "gstpeaq_amd" / "csrc").glob("*")):
+        if f.is_file():
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def profile_numbers():
-    """Counter-derived figures of the front end.  They are NOT measured in this run: they come from
-    separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh, tools/pmc_mix.sh),
-    committed under profiles/ together with the commit and kernel time they were taken at."""
+    """Counter-derived figures of the front end and the back end.  They are NOT measured in this run: they come
+    from separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh, tools/pmc_mix.sh),
+    committed under profiles/ together with the commit, the hash of the kernel sources and the kernel time they
+    were taken at.  A profile taken from other sources than the ones present is marked stale."""
     out = dict(traffic=None, valu_per_wave=None, from_profile=None)
     prof = ROOT / "profiles" / "pmc_frontend.json"
     if prof.exists():
@@ -185,7 +200,13 @@ def profile_numbers():
             out["traffic"] = d.get("hbm_bytes_per_launch")
             out["valu_per_wave"] = d.get("valu_insts_per_wave")
             out["fp64_per_wave"] = d.get("valu_fp64_insts_per_wave")
+            be = d.get("backend_kernel<109,false>", {})
+            out["be_valu_per_wave_frame"] = be.get("valu_insts_per_wave_frame")
+            out["be_fp64_per_wave_frame"] = be.get("valu_fp64_insts_per_wave_frame")
+            now = source_hash()
             out["from_profile"] = dict(file="profiles/pmc_frontend.json", commit=d.get("commit"),
+                                       source_hash=d.get("source_hash"), source_hash_now=now,
+                                       stale=d.get("source_hash") != now,
                                        kernel_avg_ms_in_profile=d.get("kernel_avg_ms"),
                                        launches_in_profile=d.get("launches"))
         except Exception:
@@ -206,7 +227,11 @@ def main():
     ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--advanced", action="store_true", help="configs[2] as the main metric instead of configs[1]")
     ap.add_argument("--no-advanced", action="store_true", help="skip the `advanced` sub-object")
+    ap.add_argument("--reduced-precision", action="store_true",
+                    help="with --advanced: time the engine's default (split-FP16 FIR) instead of the all-FP64 engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scaling-reference", action="store_true",
+                    help="skip the waves-mode pass that makes an N = 1 line comparable with N > 1 lines")
     args = ap.parse_args()
 
     import numpy as np
@@ -239,6 +264,8 @@ def main():
     seed_base = 1                                            # pair i of the job carries seed seed_base + i
 
     ctx = gstpeaq_amd.Context(local_rank)
+    if args.advanced and not args.reduced_precision:
+        ctx.set_fir_mode("f64")      # configs[2] as the main metric: at the reference's precision (see `advanced` below)
     ref, test = gstpeaq_amd.synth_fill(ctx, seed_base + lo, wave_pairs, args.channels, n_samples, device=dev)
     results = torch.empty((hi - lo, 16), dtype=torch.float64, device=dev)
     torch.cuda.synchronize(dev)
@@ -283,11 +310,15 @@ def main():
     def measure(advanced, steps, warmup):
         timed, wall, timing = run_steps(advanced, steps, warmup)
         timed, wall = reduce_max(timed), reduce_max(wall)
-        # the one collective of the path: gather the per-pair result records
+        # the one collective of the path: gather the per-pair result records; its own time
+        torch.cuda.synchronize(dev)
+        tg = time.perf_counter()
         gathered = parallel.gather_results(results, world, dist)
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - tg) * 1e3
         frame_pairs_all = float(gathered[:, 14].sum().item())
         frame_pairs_rank = float(results[:, 14].sum().item())
-        return dict(timed=timed, wall=wall, timing=timing, gathered=gathered, fp_all=frame_pairs_all,
+        return dict(timed=timed, wall=wall, timing=timing, gathered=gathered, fp_all=frame_pairs_all, gather_ms=gather_ms,
                     fp_rank=frame_pairs_rank, rows=results[: min(4096, hi - lo)].cpu().numpy().copy())
 
     def frontend_roofline(m, advanced):
@@ -300,13 +331,21 @@ def main():
         fe_s = timing["frontend_ms"] * 1e-3
         achieved = fp_last * ALGO_BYTES_PER_FRAME_PAIR / fe_s / 1e9 if fe_s > 0 else 0.0
         prof = profile_numbers()
-        valu_frac = None
+        valu_frac = step_valu_frac = None
         if prof.get("valu_per_wave") and not advanced and fe_s > 0:
-            # FP64 VALU instructions occupy a SIMD for 4 cycles per wave, all others for 2
-            # (MI355X_MICROARCH.md: SIMD-32, FP64 at half the FP32 rate); 1024 SIMDs at 2.4 GHz
+            # One issue model everywhere: an FP64 vector instruction occupies a SIMD for 4 cycles
+            # per wave, every other one for 2 (MI355X_MICROARCH.md: SIMD-32, FP64 at half the FP32 rate;
+            # profiles/r02_microbench.txt measures 4.5-5.4 and 2.4-2.9 for back-to-back FMAs); 1024 SIMDs, 2.4 GHz.
+            # Instruction counts per wave from the committed counter profile, times from THIS run's HIP events.
             f64 = prof.get("fp64_per_wave") or 0.0
             cyc = f64 * 4 + (prof["valu_per_wave"] - f64) * 2
-            valu_frac = fp_last * args.channels * 2 * cyc / (1024 * 2.4e9) / fe_s
+            fe_issue_s = fp_last * args.channels * 2 * cyc / (1024 * 2.4e9)
+            valu_frac = fe_issue_s / fe_s
+            if prof.get("be_valu_per_wave_frame") and timing["total_ms"] > 0:
+                b64 = prof.get("be_fp64_per_wave_frame") or 0.0
+                be_cyc = b64 * 4 + (prof["be_valu_per_wave_frame"] - b64) * 2
+                be_issue_s = fp_last * args.channels * be_cyc / (1024 * 2.4e9)
+                step_valu_frac = (fe_issue_s + be_issue_s) / (timing["total_ms"] * 1e-3)
         launches = max(timing["frontend_launches"], 1)
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": prof["traffic"],
@@ -315,8 +354,12 @@ def main():
                 "algorithmic_bytes_per_launch": fp_last * ALGO_BYTES_PER_FRAME_PAIR / launches,
                 "compute_frac_fp64_vector": fp_last / fe_s * FLOP_PER_FRAME_PAIR / (FP64_VECTOR_PEAK_TFLOPS * 1e12)
                 if fe_s > 0 else None,
-                "valu_issue_frac": valu_frac, "from_profile": prof["from_profile"],
-                "from_profile_fields": ["traffic", "valu_issue_frac"],
+                "valu_issue_frac": valu_frac, "step_valu_issue_frac": step_valu_frac,
+                "valu_issue_model": "4 cycles per FP64 vector instruction and wave, 2 per other vector instruction; "
+                                    "kernel: front-end instructions / front-end kernel time; step: front + back end / "
+                                    "whole step (HIP events of this run; instruction counts per wave from_profile)",
+                "from_profile": prof["from_profile"],
+                "from_profile_fields": ["traffic", "valu_issue_frac", "step_valu_issue_frac"],
                 "backend_ms": timing["backend_ms"], "fb_ms": timing["fb_ms"], "step_ms_events": timing["total_ms"]}
 
     def filterbank_roofline(m):
@@ -383,62 +426,103 @@ def main():
             "odg_mean": float(odg[~torch.isnan(odg)].mean().item()),
             "odg_nan": int(torch.isnan(odg).sum().item()),
         }
+        line["per_gpu_value"] = value / world
+        line["result_gather_ms"] = m["gather_ms"]           # after the timed region; 128 B per pair
         if waves_mode:
             line["wall_ms_per_step_incl_generation"] = m["wall"] / args.steps * 1e3
+            line["scaling_note"] = ("every rank runs the waves regime; compare per_gpu_value with "
+                                    "`scaling_reference.value` of the N = 1 line (same regime on one GPU), not with its `value`")
     rows_main = m["rows"]
 
     # ---- configs[2] next to configs[1] in the same line ---------------------------------------------
+    # `advanced.value` is the engine at the REFERENCE's precision (every stage FP64, PEAQ_FIR_F64: the mode the
+    # 1e-9 / 1e-7 parity tests hold), with the roofline of ITS bank kernel from this run's HIP events; the
+    # engine's default (split-FP16 FIR + FP32 slopes / spreading, what ships) is the labelled sub-object
+    # `reduced_precision_default` with its own roofline and its deviation from the FP64 engine on these pairs.
     adv = None
+    rows_adv = None
     if not main_adv and not args.no_advanced:
         adv_steps = max(1, min(args.steps, 3))
-        ma = measure(True, adv_steps, 1)
-        if rank == 0:
-            adv = {"config": line["config"]["workload"].replace("Basic PEAQ", "Advanced PEAQ").replace("configs[1]", "configs[2]"),
-                   "metric": "FFT frame-pairs/sec (advanced PEAQ: 55-band FFT model + 40-band filter bank, 5 MOVs)",
-                   "value": ma["fp_all"] * adv_steps / ma["timed"], "unit": "frame-pairs/s", "steps": adv_steps,
-                   "warmup": 1, "ms_per_step": ma["timed"] / adv_steps * 1e3,
-                   "fb_blocks_per_frame_pair": float(ma["gathered"][:, 15].sum().item()) / max(ma["fp_all"], 1.0),
-                   "dtype": "f64, FIR bank of the filter-bank ear model on " + {
-                       "f64": "v_mfma_f64", "f32": "v_mfma_f32 (max |dODG| 5e-8 vs all-FP64, profiles/r02_precision_ledger.json)",
-                       "f16x3": "v_mfma_f32_16x16x32_f16 with both operands split into two FP16 parts, three products per term "
-                                "and FP32 slopes / upward spreading (max |dODG| vs the all-FP64 engine: 5e-7 over the 78 cases "
-                                "of profiles/r02_precision_ledger.json; over this run's pairs see all_fp64)"}[ctx.fir_mode()],
-                   "roofline": filterbank_roofline(ma),
-                   "odg_mean": float(ma["gathered"][:, 12][~torch.isnan(ma["gathered"][:, 12])].mean().item())}
-        rows_adv = ma["rows"]
-        # the same workload with every stage in FP64 (PEAQ_FIR_F64), so that the line also carries the rate at the
-        # reference's own precision and the deviation of the default engine from it on these very pairs
-        if ctx.fir_mode() != "f64":
-            mode = ctx.fir_mode()
+        default_mode = ctx.fir_mode()
+        wl = line["config"]["workload"].replace("Basic PEAQ", "Advanced PEAQ").replace("configs[1]", "configs[2]") if rank == 0 else ""
+        try:
+            ctx.set_fir_mode("f64")
+            m64 = measure(True, adv_steps, 1)
+            if rank == 0:
+                adv = {"config": wl,
+                       "metric": "FFT frame-pairs/sec (advanced PEAQ: 55-band FFT model + 40-band filter bank, 5 MOVs)",
+                       "value": m64["fp_all"] * adv_steps / m64["timed"], "unit": "frame-pairs/s", "steps": adv_steps,
+                       "warmup": 1, "ms_per_step": m64["timed"] / adv_steps * 1e3,
+                       "fb_blocks_per_frame_pair": float(m64["gathered"][:, 15].sum().item()) / max(m64["fp_all"], 1.0),
+                       "dtype": "f64 (every stage, like the reference; FIR bank of the filter-bank ear model on v_mfma_f64_16x16x4_f64)",
+                       "engine": "PEAQ_FIR_F64 (peaq_ctx_set_fir_mode); NOT the engine's default, see reduced_precision_default",
+                       "roofline": filterbank_roofline(m64),
+                       "odg_mean": float(m64["gathered"][:, 12][~torch.isnan(m64["gathered"][:, 12])].mean().item())}
+            rows_adv = m64["rows"]
+        except Exception as e:                               # the bench line must survive this leg
+            if rank == 0:
+                adv = {"error": repr(e)[:300]}
+        finally:
+            ctx.set_fir_mode(default_mode)
+        if default_mode != "f64":
             try:
-                ctx.set_fir_mode("f64")
-                m64 = measure(True, min(adv_steps, 2), 1)
-                if rank == 0:
-                    a, b = ma["rows"][:, 12], m64["rows"][:, 12]
-                    ok = ~(np.isnan(a) | np.isnan(b))
-                    adv["all_fp64"] = {"value": m64["fp_all"] * min(adv_steps, 2) / m64["timed"], "unit": "frame-pairs/s",
-                                       "odg_max_abs_delta_default_vs_fp64": float(np.max(np.abs(a[ok] - b[ok]))) if ok.any() else None,
-                                       "pairs": int(ok.sum())}
-            except Exception as e:                           # the bench line must survive this leg
-                if rank == 0:
-                    adv["all_fp64_error"] = repr(e)[:300]
-            finally:
-                ctx.set_fir_mode(mode)
+                ma = measure(True, adv_steps, 1)
+                if rank == 0 and adv is not None:
+                    sub = {"value": ma["fp_all"] * adv_steps / ma["timed"], "unit": "frame-pairs/s", "steps": adv_steps,
+                           "ms_per_step": ma["timed"] / adv_steps * 1e3,
+                           "dtype": "FIR bank on v_mfma_f32_16x16x32_f16 with both operands split into two FP16 parts (three "
+                                    "products per term, FP32 accumulation), slopes and upward spreading FP32, everything else "
+                                    "FP64: narrower than the reference's arithmetic, hence not the headline",
+                           "engine": f"{default_mode} (the engine's default)",
+                           "roofline": filterbank_roofline(ma)}
+                    if rows_adv is not None:
+                        a, b = ma["rows"][:, 12], rows_adv[:, 12]
+                        ok = ~(np.isnan(a) | np.isnan(b))
+                        sub["odg_max_abs_delta_vs_fp64_engine"] = float(np.max(np.abs(a[ok] - b[ok]))) if ok.any() else None
+                        sub["pairs"] = int(ok.sum())
+                    adv["reduced_precision_default"] = sub
+            except Exception as e:
+                if rank == 0 and adv is not None:
+                    adv["reduced_precision_default"] = {"error": repr(e)[:300]}
 
-    # ---- CPU legs: rank 0, single GPU only (they would disturb the other ranks' timing otherwise) ------
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    # ---- the scaling regime on this GPU (N = 1 only): what every rank of an N > 1 run does -- 32 768 pairs
+    # consumed in synchronised waves of 4096 -- so that an efficiency computed from the driver's N = 1, 2, 4, 8
+    # lines can compare like with like (`scaling_reference.value`, not `value`, is the per-GPU rate of that regime)
+    if world == 1 and not waves_mode and not main_adv and not args.no_scaling_reference and args.pairs is None \
+            and rank == 0:
+        try:
+            wr = torch.empty((CONFIG4_PAIRS_PER_GPU, 16), dtype=torch.float64, device=dev)
+            barrier()
+            timed_w = parallel.run_waves(ctx, False, seed_base, CONFIG4_PAIRS_PER_GPU, pairs_per_gpu, ref, test, wr)
+            barrier()
+            line["scaling_reference"] = {
+                "value": float(wr[:, 14].sum().item()) / timed_w, "unit": "frame-pairs/s",
+                "mode": f"waves: {CONFIG4_PAIRS_PER_GPU} pairs on this GPU in {CONFIG4_PAIRS_PER_GPU // pairs_per_gpu} "
+                        f"device-synchronised waves of {pairs_per_gpu} (generation between the timed regions), exactly "
+                        "what every rank of `--gpus N`, N > 1, runs; `value` above is the pipelined single-batch regime",
+                "ms_per_wave": timed_w / (CONFIG4_PAIRS_PER_GPU // pairs_per_gpu) * 1e3}
+            del wr
+            gstpeaq_amd.synth_fill(ctx, seed_base + lo, wave_pairs, args.channels, n_samples, out=(ref, test))
+        except Exception as e:
+            line["scaling_reference"] = {"error": repr(e)[:300]}
+
+    # ---- CPU legs: rank 0.  At N = 1 one core, all usable cores, and the advanced version's leg; at N > 1 the
+    # one-core leg only (the other ranks wait at the final barrier meanwhile; nothing is being timed any more).
+    if rank == 0 and not args.no_cpu_baseline:
         try:
             base, cpu = cpu_single(n_samples, args.channels, seed_base + lo, main_adv, 12.0)
             line["cpu_baseline"] = base
             line.update(result_deltas(rows_main, cpu, main_adv))
             line["delta_vs"] = base["kind"]
-            allc = cpu_all_cores(n_samples, args.channels, seed_base + lo, main_adv)
-            if allc:
-                line["cpu_baseline"]["all_cores"] = allc
-            if adv is not None:
-                abase, acpu = cpu_single(n_samples, args.channels, seed_base + lo, True, 5.0)
-                adv["cpu_baseline"] = abase
-                adv.update(result_deltas(rows_adv, acpu, True))
+            if world == 1:
+                allc = cpu_all_cores(n_samples, args.channels, seed_base + lo, main_adv)
+                if allc:
+                    line["cpu_baseline"]["all_cores"] = allc
+                if adv is not None and rows_adv is not None:
+                    abase, acpu = cpu_single(n_samples, args.channels, seed_base + lo, True, 16.0)   # >= 32 pairs
+                    adv["cpu_baseline"] = abase
+                    adv.update(result_deltas(rows_adv, acpu, True))
+                    adv["delta_vs"] = abase["kind"]
         except Exception as e:                               # the bench line must survive a broken baseline leg
             line["cpu_baseline_error"] = repr(e)[:300]
     if rank == 0:

@@ -17,6 +17,7 @@ stats = json.loads((G / "stats_basic.json").read_text())
 fe = next(v for k, v in d.items() if "frontend_kernel<109>" in k)
 be = next(v for k, v in d.items() if "backend_kernel<109" in k)
 fm = next(v for k, v in mix.items() if "frontend_kernel<109>" in k)
+bm = next(v for k, v in mix.items() if "backend_kernel<109" in k)
 launches = fe["FETCH_SIZE"]["dispatches"]
 pairs, frames, algo = 4096, 468, 16384
 algo_launch = pairs * frames * algo / launches
@@ -25,6 +26,13 @@ wr = fe["WRITE_SIZE"]["avg"] * 1024
 w = fm["SQ_WAVES"]["avg"]
 fp64 = sum(fm[c]["avg"] for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
                                   "SQ_INSTS_VALU_TRANS_F64")) / w
+sys.path.insert(0, str(ROOT))
+from bench import source_hash  # noqa: E402
+# back end: instructions per wave and FRAME (a wave walks all 468 frames of its pair and channel over the launches)
+be_wave_frames = bm["SQ_WAVES"]["avg"] * frames
+be_valu = bm["SQ_INSTS_VALU"]["sum"] / be_wave_frames
+be_fp64 = sum(bm[c]["sum"] for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
+                                     "SQ_INSTS_VALU_TRANS_F64")) / be_wave_frames
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 kavg = next(k["avg_us"] for k in stats["kernels"] if "frontend_kernel<109>" in k["kernel"]) / 1e3
 out = {
@@ -33,6 +41,7 @@ out = {
     "_units": "bytes per dispatch, averaged over the front-end launches of one pass; FETCH_SIZE (KiB) doubled "
               "(gfx950 correction, MI355X_MICROARCH.md HBM section), WRITE_SIZE (KiB) as is",
     "commit": commit,
+    "source_hash": source_hash(),
     "kernel": "frontend_kernel<109>",
     "kernel_avg_ms": kavg,
     "launches": launches,
@@ -55,6 +64,9 @@ out = {
     "backend_kernel<109,false>": {
         "hbm_read_bytes_per_launch": be["FETCH_SIZE"]["avg"] * 1024 * 2,
         "hbm_write_bytes_per_launch": be["WRITE_SIZE"]["avg"] * 1024,
+        "valu_insts_per_wave_frame": be_valu,
+        "valu_fp64_insts_per_wave_frame": be_fp64,
+        "lds_insts_per_wave_frame": bm["SQ_INSTS_LDS"]["sum"] / be_wave_frames,
     },
 }
 (ROOT / "profiles" / "pmc_frontend.json").write_text(json.dumps(out, indent=1) + "\n")
