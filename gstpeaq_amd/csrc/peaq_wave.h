@@ -258,10 +258,9 @@ __device__ __forceinline__ double log_pos(double x) {
   m = low ? m + m : m;
   e = low ? e - 1 : e;
   const double num = m - 1., den = m + 1.;           // both exact
-  double r = __builtin_amdgcn_rcp(den);              // den in [1.7, 2.42): two Newton steps, then
-  r = fma(fma(-den, r, 1.), r, r);                   // the quotient with one residual correction
-  r = fma(fma(-den, r, 1.), r, r);
-  double s = num * r;
+  double r = __builtin_amdgcn_rcp(den);              // den in [1.7, 2.42): one Newton step (the hardware's
+  r = fma(fma(-den, r, 1.), r, r);                   // reciprocal is good to ~2^-26, squared: 2^-52), then the
+  double s = num * r;                                // quotient with one residual correction (error x error)
   s = fma(fma(-den, s, num), r, s);
   const double z = s * s;
   double p = 1. / 19;
@@ -310,25 +309,22 @@ __device__ __forceinline__ double exp_fast(double x) {
 }
 
 // a / b for finite b of moderate magnitude (no scaling against overflow / underflow of the
-// reciprocal, no special cases): reciprocal with two Newton steps, quotient with one residual
-// correction; <= 1 ulp.  8 instructions instead of the 11 of the IEEE sequence.
+// reciprocal, no special cases): reciprocal with ONE Newton step (2^-26 -> 2^-52), quotient with one
+// residual correction, whose error is the product of the quotient's and the reciprocal's: <= 1 ulp
+// (tools/check_math.hip).  6 instructions instead of the 11 of the IEEE sequence.
 __device__ __forceinline__ double div_fast(double a, double b) {
   double r = __builtin_amdgcn_rcp(b);
-  r = fma(fma(-b, r, 1.), r, r);
   r = fma(fma(-b, r, 1.), r, r);
   const double q = a * r;
   return fma(fma(-b, q, a), r, q);
 }
 
-// sqrt(x) for finite x >= 0 (0 -> 0), <= 1 ulp: reciprocal square root, two coupled Newton steps
-// on (sqrt, 1/(2 sqrt)), one residual correction.  14 instructions instead of 23.
+// sqrt(x) for finite x >= 0 (0 -> 0), <= 1 ulp: reciprocal square root, ONE coupled Newton step
+// on (sqrt, 1/(2 sqrt)), one residual correction (tools/check_math.hip).  11 instructions instead of 23.
 __device__ __forceinline__ double sqrt_pos(double x) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
   double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  r = fma(-h, g, 0.5);
   g = fma(g, r, g);
   h = fma(h, r, h);
   g = fma(fma(-g, g, x), h, g);
