@@ -169,6 +169,9 @@ struct GlobalTabs {
   __device__ __forceinline__ double ln_internal_noise(int b) const { return p->ln_internal_noise[b]; }
   __device__ __forceinline__ double inv_window_count(int b) const { return p->inv_window_count[b]; }
   __device__ __forceinline__ double deriv_factor() const { return p->deriv_factor; }
+  // transcendentals of the MOV layer: the polynomial forms (peaq_wave.h)
+  __device__ __forceinline__ double log(double x) const { return be_log(x); }
+  __device__ __forceinline__ double pow(double x, double y) const { return be_pow(x, y); }
 };
 enum { T_ADAPT, T_EAR, T_THR, T_LOUDF, T_EXCTHR, T_INOISE, T_NPOW03, T_MASK, T_ISN, T_ISN03, T_LNINOISE, T_RCNT, T_COUNT };
 struct LdsTabs {
@@ -187,6 +190,16 @@ struct LdsTabs {
   __device__ __forceinline__ double ln_internal_noise(int b) const { return at(T_LNINOISE, b); }
   __device__ __forceinline__ double inv_window_count(int b) const { return at(T_RCNT, b); }
   __device__ __forceinline__ double deriv_factor() const { return deriv; }
+  // transcendentals of the MOV layer: the logarithm from the 129-entry table in LDS (log_tab, peaq_wave.h) --
+  // ten logarithms per band and frame are a tenth of this kernel's vector instructions otherwise
+  const double* ltab;               // [kLogTabEntries][2] in LDS
+#if defined(PEAQ_LEDGER_FP32_BACKEND) || defined(PEAQ_NO_LOGTAB_BE)
+  __device__ __forceinline__ double log(double x) const { return be_log(x); }
+  __device__ __forceinline__ double pow(double x, double y) const { return be_pow(x, y); }
+#else
+  __device__ __forceinline__ double log(double x) const { return log_tab(x, ltab); }
+  __device__ __forceinline__ double pow(double x, double y) const { return be_exp(y * log_tab(x, ltab)); }
+#endif
 };
 
 // leveladapter.c:243-340.  e_ref/e_test: excitation patterns of this frame.
@@ -298,7 +311,7 @@ __device__ __forceinline__ double total_loudness(const BandLane<NB, SLOTS>& bl, 
     if (bl.valid(s)) {
       const int b = bl.band(s);
       const double thr = bt.threshold(b);
-      const double l = bt.loud_factor(b) * (be_pow(1. - thr + div_fast(thr * exc[s], bt.exc_threshold(b)), 0.23) - 1.);
+      const double l = bt.loud_factor(b) * (bt.pow(1. - thr + div_fast(thr * exc[s], bt.exc_threshold(b)), 0.23) - 1.);
       t += fmax(l, 0.);
     }
   }
@@ -320,8 +333,8 @@ __device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, 
       const double ethres = bt.internal_noise(bl.band(s));
       const double beta = be_exp(div_fast(-alpha * (e_test[s] - e_ref[s]), e_ref[s]));
       // (ethres / stest)^0.23 from the logarithms: ln ethres is a table entry
-      nl += be_exp(0.23 * (bt.ln_internal_noise(bl.band(s)) - be_log(stest))) *
-            (be_pow(1. + div_fast(fmax(stest * e_test[s] - sref * e_ref[s], 0.), ethres + sref * e_ref[s] * beta), 0.23) -
+      nl += be_exp(0.23 * (bt.ln_internal_noise(bl.band(s)) - bt.log(stest))) *
+            (bt.pow(1. + div_fast(fmax(stest * e_test[s] - sref * e_ref[s], 0.), ethres + sref * e_ref[s] * beta), 0.23) -
              1.);
     }
   }
@@ -374,6 +387,7 @@ template <int NB, bool ADV, bool DBG = false>
 __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
   __shared__ BackendShared sh;
   __shared__ double sh_tab[T_COUNT * kBandStride];
+  __shared__ __attribute__((aligned(16))) double sh_ltab[2 * kLogTabEntries + 2];
   constexpr int SLOTS = 2;
   const int lane = threadIdx.x & 63;
   const int chan = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keep it scalar
@@ -388,8 +402,9 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
 #pragma unroll
     for (int t = 0; t < T_COUNT; ++t)
       for (int i = threadIdx.x; i < kBandStride; i += blockDim.x) sh_tab[t * kBandStride + i] = src[t][i];
+    for (int i = threadIdx.x; i < 2 * kLogTabEntries; i += blockDim.x) sh_ltab[i] = a.common->log_tab[i >> 1][i & 1];
   }
-  LdsTabs bt{sh_tab, 0, a.bands->deriv_factor};
+  LdsTabs bt{sh_tab, 0, a.bands->deriv_factor, sh_ltab};
   PairState* __restrict__ ps = a.state + (a.pair_slot ? a.pair_slot[pair] : pair);
   ChannelState* __restrict__ cs = &ps->ch[chan];
 
@@ -537,12 +552,12 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
       for (int s = 0; s < SLOTS; ++s) {
         double pc = 0., qc = 0.;
         if (bl.valid(s)) {
-          const double er_db = (10. * kInvLn10) * be_log(er[s]);     // 10 log10: excitations are > 0
-          const double et_db = (10. * kInvLn10) * be_log(et[s]);
+          const double er_db = (10. * kInvLn10) * bt.log(er[s]);      // 10 log10: excitations are > 0
+          const double et_db = (10. * kInvLn10) * bt.log(et[s]);
           const double l = 0.3 * fmax(er_db, et_db) + 0.7 * et_db;
           const double l2 = l * l;
           // (6.39468 / l)^1.71332 = exp(1.71332 (ln 6.39468 - ln l)); one reciprocal of s for both quotients
-          const double sd = l > 0. ? 5.95072 * be_exp(1.71332 * (1.8554663946857675 - be_log(l))) + 9.01033e-11 * l2 * l2 +
+          const double sd = l > 0. ? 5.95072 * be_exp(1.71332 * (1.8554663946857675 - bt.log(l))) + 9.01033e-11 * l2 * l2 +
                                          5.05622e-6 * l2 * l - 0.00102438 * l * l + 0.0550197 * l - 0.198719
                                    : 1e30;
           const double inv_sd = div_fast(1., sd);

@@ -687,6 +687,7 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
   ba.channels = channels;
   ba.advanced = advanced ? 1 : 0;
   ba.bands = fa.bands;
+  ba.common = c->d_common;
   ba.state = c->state.as<PairState>();
 
   // Software pipeline over chunks of frames: the front end of chunk i+1 (throughput bound,
@@ -934,6 +935,7 @@ extern "C" int peaq_debug_backend(peaq_ctx* c, int channels, int n_frames, const
   ba.channels = channels;
   ba.advanced = 0;
   ba.bands = c->d_bands109;
+  ba.common = c->d_common;
   ba.state = st.as<PairState>();
   ba.debug = dbg.as<double>();
   HIP_TRY(launch_backend(ba, 1, nullptr));
@@ -1121,6 +1123,7 @@ static int session_run_frames(peaq_session* s, unsigned nf, const uint64_t n_val
   ba.channels = s->channels;
   ba.advanced = s->advanced;
   ba.bands = fa.bands;
+  ba.common = c->d_common;
   ba.state = s->state.as<PairState>();
   HIP_TRY(launch_backend(ba, 1, s->stream));
   s->frames_done += nf;
@@ -1684,6 +1687,7 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
     ba.channels = b->channels;
     ba.advanced = b->advanced;
     ba.bands = fa.bands;
+    ba.common = c->d_common;
     ba.state = b->state.as<PairState>();
     ba.pair_frame0 = fa.pair_frame0;
     ba.pair_nframes = fa.pair_nframes;

@@ -62,7 +62,19 @@ struct CommonTables {
   double ear_w2_pair[8][64][2]; // ear_w2 of bin l + 64 q and of its mirror bin (spec_bin(8 + q, l)), q = 0..7
   double ehs_window[256];       // movs.c:1366-1367
   double ehs_window_centred[256];   // movs.c:1363-1364 (CENTER_EHS_CORRELATION_WINDOW)
+  // Logarithm by table (log_tab, peaq_wave.h): x = m 2^e with m in [0.5, 1); bin i = round(128 (2 m - 1)),
+  // i = 0..128, holds the mantissas with 2 m in [C - 1/256, C + 1/256) around the centre C = 1 + i / 128:
+  //   [i][0] = 2 / C              r = m [i][0] - 1 = 2 m / C - 1,  |r| <= 2^-8
+  //   [i][1] = ln C - ln 2        (i >= kLogTabFold: ln x = e ln 2 + [i][1] + log1p(r))
+  //            ln C               (i <  kLogTabFold: the same with e - 1 -- the lower bins are read as
+  //                                [1, sqrt 2) of the binade BELOW)
+  // Arguments around 1 fall into bin 0 (from above) or bin 128 (from below), whose entries are exactly
+  // {2, 0} and {1, 0}: there r = x - 1 exactly and the power of two counts 0, so ln 1 = 0 and the
+  // relative accuracy holds however close to 1 the argument is.
+  double log_tab[130][2];
 };
+constexpr int kLogTabEntries = 129;
+constexpr int kLogTabFold = 54;     // first bin whose centre lies above sqrt 2
 
 struct BandTables {             // earmodel.c:279-323 + fftearmodel.c:693-788
   int    bands;

@@ -53,7 +53,8 @@ constexpr int kUnitDoubles = 1288;
 constexpr int kOffPw = 0;                     // Pw[776]
 constexpr int kOffScratch = 776;              // 512 doubles
 constexpr int kPwLen = 776;
-constexpr int kLdsDoubles = 2 * kUnitDoubles;
+constexpr int kOffLogTab = 2 * kUnitDoubles;       // the logarithm table (log_tab, peaq_wave.h) behind both units
+constexpr int kLdsDoubles = 2 * kUnitDoubles + 2 * kLogTabEntries + 2;
 #ifndef PEAQ_FE_WAVES
 #define PEAQ_FE_WAVES 3
 #endif
@@ -395,6 +396,7 @@ void frontend_kernel(FrontendArgs a) {
                                  -0.9229222721777677728372, -0.705205101457706221079, -0.3800232782373413192215};
   const double2 hl0 = *reinterpret_cast<const double2*>(&ct->hann_lane[lane][0]);
   const double2 hl1 = *reinterpret_cast<const double2*>(&ct->hann_lane[lane][2]);
+  double* ltab = lds + kOffLogTab;                   // the logarithm table, copied in after the transform (below)
   FE_MARK(13);                                       // work-item decoding, pointers
   cplx z[16];
   float amax = 0.f;
@@ -490,6 +492,19 @@ void frontend_kernel(FrontendArgs a) {
   double pspec[16];                                  // unweighted power spectrum, bin lane + 64 q
   frame_power_spectrum(z, pspec, unit, lane, ct, a.level_factor);
 
+  // The logarithm table (log_tab, peaq_wave.h) into LDS, by the reference wave only and here, where its registers
+  // have just become free: its first reader is the spreading phase -- of this wave, in program order, and of
+  // the test wave only behind the barriers of the bandwidth search (the 55-band kernel's test wave reads it
+  // behind the barrier that follows the spreading phase).
+  if (sig == 0) {
+    const double2 t0 = *reinterpret_cast<const double2*>(ct->log_tab[lane]);
+    const double2 t1 = *reinterpret_cast<const double2*>(ct->log_tab[64 + lane]);
+    const double2 t2 = *reinterpret_cast<const double2*>(ct->log_tab[128]);
+    reinterpret_cast<double2*>(ltab)[lane] = t0;
+    reinterpret_cast<double2*>(ltab)[64 + lane] = t1;
+    if (lane == 0) reinterpret_cast<double2*>(ltab)[128] = t2;
+    wave_lds_fence();
+  }
   FE_MARK(1);                                        // FFT + split
   // ---- bandwidths (movs.c:776-809) on the unweighted spectra, straight from the registers.
   // Both waves are in lock step here, the two barriers are cheap.
@@ -580,13 +595,13 @@ void frontend_kernel(FrontendArgs a) {
         // Kabal (23)-(24); fftearmodel.c:649-656.  a^y evaluated as exp(y ln a); the three powers of
         // aUCE share one exponential (t = aUCE^0.2: aUCE^0.4 = t^2, aUCE = t^5), and En^0.4 takes its
         // logarithm as ln Pp - ln(gIL + gIU - 1) instead of dividing first
-        const double ln_pp = log_pos(pp);
+        const double ln_pp = FE_LOG(pp, ltab);
         const double ln_a = bt->ln_aUC[b] + bt->dz02 * ln_pp;
         const double t = exp_fast(0.2 * ln_a), t2 = t * t;
         const double a_uce = t2 * t2 * t;
         const double g_iu = div_fast(1. - exp_fast((double)(NB - b) * ln_a), 1. - a_uce);
         ae[s] = t2;
-        ene[s] = exp_fast(0.4 * (ln_pp - log_pos(bt->gIL[b] + g_iu - 1.)));
+        ene[s] = exp_fast(0.4 * (ln_pp - FE_LOG(bt->gIL[b] + g_iu - 1., ltab)));
       } else {
         ae[s] = 0.;
         ene[s] = 0.;
@@ -648,7 +663,7 @@ void frontend_kernel(FrontendArgs a) {
       if (sig == 0 && j >= 2) break;
       const int k = (sig == 0 ? 0 : 128) + lane + 64 * j;
       const double fr = pw_ref[k], ft = pw_test[k];
-      dlog[k] = (fr == 0. && ft == 0.) ? 0. : log_nonneg(ft / fr);   // +-inf when one side is digital silence
+      dlog[k] = (fr == 0. && ft == 0.) ? 0. : FE_LOG_NONNEG(ft / fr, ltab);   // +-inf when one side is digital silence
     }
   }
   FE_MARK(8);                                        // log ratios

@@ -57,6 +57,7 @@ struct BackendArgs {
   uint32_t n_frames_uniform;
   int channels;
   int advanced;                 // 0: basic (109 bands, 11 MOVs); 1: FFT part of advanced (55 bands)
+  const CommonTables* common;   // log_tab
   const BandTables* bands;
   PairState* state;             // [pair]
   // broker launches: per-pair frame window and state slot (see FrontendArgs)

@@ -306,6 +306,16 @@ void build_common_tables(CommonTables& c) {
     c.ehs_window[i] = 0.81649658092773 * (1.0 - std::cos(2 * kPi * i / 255.0)) / 256.0;
     c.ehs_window_centred[i] = 0.81649658092773 * (1.0 + std::cos(2 * kPi * i / 511.0)) / 256.0;
   }
+  for (int i = 0; i < 130; ++i) {                     // log_tab (peaq_device.h)
+    const long double centre = 1.0L + i / 128.0L, ln2 = 0.693147180559945309417232121458176568L;
+    c.log_tab[i][0] = (double)(2.0L / centre);
+    // the centre that the ROUNDED reciprocal stands for: r = fma(m, [i][0], -1) is then exact with respect to it,
+    // and the only rounding left in ln m = log1p(r) + ln C - ln 2 is that of the entry itself
+    const long double c_eff = 2.0L / (long double)c.log_tab[i][0];
+    // the lower bins count one binade less in e instead of carrying - ln 2
+    c.log_tab[i][1] = (double)(i < kLogTabFold ? std::log(c_eff) : std::log(c_eff) - ln2);
+  }
+  c.log_tab[128][1] = 0.;                             // ln 2 - ln 2 (the long-double difference is 0 anyway)
 }
 
 double fft_level_factor(double level_db) {

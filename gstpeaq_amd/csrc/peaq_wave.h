@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "peaq_device.h"
+
 namespace peaq {
 
 struct cplx {
@@ -276,6 +278,44 @@ __device__ __forceinline__ double log_pos(double x) {
   const double lm = fma(t * z, p, t);                // 2 s (1 + z P(z))
   const double ef = (double)e;
   return fma(ef, 6.93147180369123816490e-01, fma(ef, 1.90821492927058770002e-10, lm));
+}
+
+// ln x for finite x > 0 (subnormals included) from the 129-entry table CommonTables::log_tab, which the caller
+// holds in LDS (`tab`: {2 / C, ln C [- ln 2]} per bin): x = m 2^e, the bin is the nearest multiple of 1/128 to the
+// fraction of 2 m, r = 2 m / C - 1 with |r| <= 2^-8, log1p(r) = r - r^2/2 + ... - r^6/6 (truncation 2^-56 / 7), and
+// the power of two joins the entry in one multiply-add (relative error of that product: ln 2's, 1e-17).
+// 17 vector instructions and one 16-byte LDS read against 31 of log_pos; <= 2 ulp like log_pos, <= 5 ulp for
+// arguments around 1 (their bins have the centre 1: r = x - 1 exactly, ln 1 = 0 exactly); tools/check_math.hip.
+// Measured (same box, 4096 pairs): +2.3 % frame-pairs/s for the basic version with the front end's and the back
+// end's logarithms from the table -- the vector ALU is what the step is bound by, the LDS reads cost less.
+__device__ __forceinline__ double log_tab(double x, const double* __restrict__ tab) {
+  const double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  // fraction bits 51..45 of m, rounded to nearest: the carry of an all-ones fraction lands in the exponent's
+  // lowest bit, which is 0 for [0.5, 1) -- so bits 20..13 of the high word read 0..128
+  const unsigned idx = __builtin_amdgcn_ubfe((unsigned)__double2hiint(m) + 0x1000u, 13, 8);
+  const double2 t = *reinterpret_cast<const double2*>(tab + 2 * idx);
+  e -= idx < (unsigned)kLogTabFold ? 1 : 0;
+  const double r = fma(m, t.x, -1.);
+  double p = -1. / 6;
+  p = fma(p, r, 1. / 5);
+  p = fma(p, r, -1. / 4);
+  p = fma(p, r, 1. / 3);
+  p = fma(p, r, -0.5);
+  const double l1p = fma(r * r, p, r);
+  return fma((double)e, 6.93147180559945286227e-01, t.y) + l1p;
+}
+#ifdef PEAQ_NO_LOGTAB_FE
+#define FE_LOG(x, tab) log_pos(x)
+#define FE_LOG_NONNEG(x, tab) log_nonneg(x)
+#else
+#define FE_LOG(x, tab) log_tab(x, tab)
+#define FE_LOG_NONNEG(x, tab) log_tab_nonneg(x, tab)
+#endif
+// any x >= 0 or NaN, like log_nonneg below
+__device__ __forceinline__ double log_tab_nonneg(double x, const double* __restrict__ tab) {
+  const double l = log_tab(x, tab);
+  return x == 0. ? -__builtin_inf() : (x == __builtin_inf() ? __builtin_inf() : l);
 }
 
 // the same for any x >= 0 or NaN: ln 0 = -inf, ln inf = inf (digital silence reaches the
