@@ -169,9 +169,15 @@ struct GlobalTabs {
   __device__ __forceinline__ double ln_internal_noise(int b) const { return p->ln_internal_noise[b]; }
   __device__ __forceinline__ double inv_window_count(int b) const { return p->inv_window_count[b]; }
   __device__ __forceinline__ double deriv_factor() const { return p->deriv_factor; }
-  // transcendentals of the MOV layer: the polynomial forms (peaq_wave.h)
+  // transcendentals of the MOV layer: the logarithm from the table in LDS (see LdsTabs)
+  const double* ltab;
+#if defined(PEAQ_LEDGER_FP32_BACKEND) || defined(PEAQ_NO_LOGTAB_BE)
   __device__ __forceinline__ double log(double x) const { return be_log(x); }
   __device__ __forceinline__ double pow(double x, double y) const { return be_pow(x, y); }
+#else
+  __device__ __forceinline__ double log(double x) const { return log_tab(x, ltab); }
+  __device__ __forceinline__ double pow(double x, double y) const { return be_exp(y * log_tab(x, ltab)); }
+#endif
 };
 enum { T_ADAPT, T_EAR, T_THR, T_LOUDF, T_EXCTHR, T_INOISE, T_NPOW03, T_MASK, T_ISN, T_ISN03, T_LNINOISE, T_RCNT, T_COUNT };
 struct LdsTabs {
@@ -740,12 +746,15 @@ struct FbBackendShared {
 
 __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
   __shared__ FbBackendShared sh;
+  __shared__ __attribute__((aligned(16))) double sh_ltab[2 * kLogTabEntries + 2];
   constexpr int NB = kFbBands, SLOTS = 1;
   const int lane = threadIdx.x & 63;
   const int chan = threadIdx.x >> 6;
   const int channels = a.channels;
   const unsigned pair = blockIdx.x;
-  const GlobalTabs bt{a.bands};
+  for (int i = threadIdx.x; i < 2 * kLogTabEntries; i += blockDim.x) sh_ltab[i] = a.common->log_tab[i >> 1][i & 1];
+  __syncthreads();
+  const GlobalTabs bt{a.bands, sh_ltab};
   const BandLane<NB, SLOTS> bl{lane};
   unsigned b_begin, b_end, slot = pair;
   if (a.windows) {                                   // broker launch: this session's own window and state
@@ -815,8 +824,8 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
     ut[0] = cur.ut;
     er[0] = cur.er;
     et[0] = cur.et;
-    lr[0] = pow_pos(ur[0], 0.3);                     // modpatt.c:235
-    lt[0] = pow_pos(ut[0], 0.3);
+    lr[0] = bt.pow(ur[0], 0.3);                      // modpatt.c:235
+    lt[0] = bt.pow(ut[0], 0.3);
     double ad_ref[SLOTS], ad_test[SLOTS], mr[SLOTS], mt[SLOTS];
     level_adapt<NB, SLOTS>(bl, bt, er, et, la, &sh.pa[chan][0][0], ad_ref, ad_test);
     modulation<NB, SLOTS>(bl, bt, lr, mdr, mr);

@@ -471,6 +471,7 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
     fbk.n_blocks_uniform = max_blocks;
     fbk.channels = channels;
     fbk.bands = c->d_bands40;
+  fbk.common = c->d_common;
     fbk.state = c->state.as<PairState>();
     // Three stages per chunk of blocks, each on its own stream: the high-pass filter (a few hundred
     // waves, latency bound), the filter bank (the bulk), the back end (one workgroup per pair).
@@ -1169,6 +1170,7 @@ static int session_run_blocks(peaq_session* s, unsigned nb, const uint64_t n_val
   fbk.n_blocks_uniform = s->blocks_done + nb;
   fbk.channels = s->channels;
   fbk.bands = c->d_bands40;
+  fbk.common = c->d_common;
   fbk.state = s->state.as<PairState>();
   HIP_TRY(launch_fb_backend(fbk, 1, s->stream));
   s->blocks_done += nb;
@@ -1726,6 +1728,7 @@ static int broker_tick_locked(peaq_broker* b, unsigned* n_active_out) {
     fbk.blocks_per_launch = max_nb;
     fbk.channels = b->channels;
     fbk.bands = c->d_bands40;
+  fbk.common = c->d_common;
     fbk.state = b->state.as<PairState>();
     fbk.windows = ff.windows;
     HIP_TRY(launch_fb_backend(fbk, fb_active, b->stream));

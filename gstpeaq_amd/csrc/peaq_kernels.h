@@ -128,6 +128,7 @@ struct FbBackendArgs {
   const uint32_t* n_blocks;
   uint32_t n_blocks_uniform;
   int channels;
+  const CommonTables* common;   // log_tab
   const BandTables* bands;
   PairState* state;
   const FbPairWindow* windows;  // broker launches
