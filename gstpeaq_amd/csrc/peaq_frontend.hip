@@ -54,7 +54,8 @@ constexpr int kOffPw = 0;                     // Pw[776]
 constexpr int kOffScratch = 776;              // 512 doubles
 constexpr int kPwLen = 776;
 constexpr int kOffLogTab = 2 * kUnitDoubles;       // the logarithm table (log_tab, peaq_wave.h) behind both units
-constexpr int kLdsDoubles = 2 * kUnitDoubles + 2 * kLogTabEntries + 2;
+constexpr int kLogTabDoubles = 2 * kLogTabEntries + 2;   // the table + two spare words, per wave
+constexpr int kLdsDoubles = 2 * kUnitDoubles + 2 * kLogTabDoubles;
 #ifndef PEAQ_FE_WAVES
 #define PEAQ_FE_WAVES 3
 #endif
@@ -396,7 +397,7 @@ void frontend_kernel(FrontendArgs a) {
                                  -0.9229222721777677728372, -0.705205101457706221079, -0.3800232782373413192215};
   const double2 hl0 = *reinterpret_cast<const double2*>(&ct->hann_lane[lane][0]);
   const double2 hl1 = *reinterpret_cast<const double2*>(&ct->hann_lane[lane][2]);
-  double* ltab = lds + kOffLogTab;                   // the logarithm table, copied in after the transform (below)
+  double* ltab = lds + kOffLogTab + sig * kLogTabDoubles;   // this wave's copy of the logarithm table (filled below)
   FE_MARK(13);                                       // work-item decoding, pointers
   cplx z[16];
   float amax = 0.f;
@@ -492,11 +493,10 @@ void frontend_kernel(FrontendArgs a) {
   double pspec[16];                                  // unweighted power spectrum, bin lane + 64 q
   frame_power_spectrum(z, pspec, unit, lane, ct, a.level_factor);
 
-  // The logarithm table (log_tab, peaq_wave.h) into LDS, by the reference wave only and here, where its registers
-  // have just become free: its first reader is the spreading phase -- of this wave, in program order, and of
-  // the test wave only behind the barriers of the bandwidth search (the 55-band kernel's test wave reads it
-  // behind the barrier that follows the spreading phase).
-  if (sig == 0) {
+  // The logarithm table (log_tab, peaq_wave.h) into LDS: every wave fills its OWN copy -- no workgroup barrier
+  // stands between the transform and the first logarithm any more -- and does so here, where its registers have
+  // just become free (at the start of the kernel the three loads would sit in front of the frame's own).
+  {
     const double2 t0 = *reinterpret_cast<const double2*>(ct->log_tab[lane]);
     const double2 t1 = *reinterpret_cast<const double2*>(ct->log_tab[64 + lane]);
     const double2 t2 = *reinterpret_cast<const double2*>(ct->log_tab[128]);
@@ -506,61 +506,53 @@ void frontend_kernel(FrontendArgs a) {
     wave_lds_fence();
   }
   FE_MARK(1);                                        // FFT + split
-  // ---- bandwidths (movs.c:776-809) on the unweighted spectra, straight from the registers.
-  // Both waves are in lock step here, the two barriers are cheap.
-  // The advanced version has no bandwidth MOVs (gstpeaq.c:924-959): its 55-band kernel skips them.
+  // ---- bandwidths (movs.c:776-809) on the unweighted spectra, straight from the registers.  The three
+  // steps hand a number from one wave to the other twice -- the test wave's zero threshold to the reference
+  // wave's search, the reference bandwidth to the test wave's search -- and ride on the two workgroup barriers
+  // the kernel has anyway (after the spreading phase, after the log ratios) instead of two of their own:
+  // a barrier is where a wave waits for its partner on another SIMD, and fewer of them is what makes the
+  // workgroup less sensitive to whatever else runs on either SIMD.  The spectra stay in
+  // registers until then.  The advanced version has no bandwidth MOVs (gstpeaq.c:924-959): its 55-band kernel
+  // skips all of this.
   constexpr bool kAdvanced = NB == 55;
   int bw_ref = 0, bw_test = 0;
-  if (!kAdvanced) {
-    // [2] exchanged scalars, at the end of the reference unit's scratch: that is beyond what the
-    // spreading phase uses and gets overwritten only after the next barrier but one
-    double* xch = lds + kOffScratch + 510;
-    double thr = 0.;                                 // powers are >= 0
-    if (sig == 1) {
-      // zero threshold = max over bins 921..1023 of the test spectrum: the mirror bins 1024 - (lane + 64 q)
-      // of q = 0 (lanes 1..63) and q = 1 (lanes 0..39)
-      if (lane >= 1) thr = pspec[8];
-      if (lane <= 39) thr = fmax(thr, pspec[9]);
-      thr = wave_max(thr);
-      if (lane == 0) xch[0] = thr;
-    }
-    __syncthreads();
-    thr = xch[0];
-    // One compare per slot; the rest is scalar: the compare's lane mask says which bins of the slot
-    // pass, its highest (slots 0..7: bin = 64 q + lane) or lowest (mirror slots: bin = 1024 - 64 q - lane)
-    // set bit below the limit is the slot's top bin.  Returns that bin + 1 over all slots, 0 if none.
-    auto top_bin = [&](double level, int limit, bool or_equal) {
-      int best = 0;
+  double* xch = lds + kOffLogTab + 2 * kLogTabEntries;   // [2] exchanged scalars: the spare words behind the first table
+  double thr = 0.;                                   // powers are >= 0
+  // One compare per slot; the rest is scalar: the compare's lane mask says which bins of the slot
+  // pass, its highest (slots 0..7: bin = 64 q + lane) or lowest (mirror slots: bin = 1024 - 64 q - lane)
+  // set bit below the limit is the slot's top bin.  Returns that bin + 1 over all slots, 0 if none.
+  auto top_bin = [&](double level, int limit, bool or_equal) {
+    int best = 0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        unsigned long long m = __ballot(or_equal ? pspec[q] >= level : pspec[q] > level);
-        const int nl = limit - 64 * q;               // lanes 0 .. nl - 1 hold bins below the limit
-        m &= nl >= 64 ? ~0ull : nl <= 0 ? 0ull : (1ull << nl) - 1ull;
-        if (m) best = max(best, 64 * q + 64 - __builtin_clzll(m));
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        unsigned long long m = __ballot(or_equal ? pspec[8 + q] >= level : pspec[8 + q] > level);
-        if (q == 0) {                                // lane 0 carries bin 512 here (spec_bin)
-          if ((m & 1ull) && 512 < limit) best = max(best, 513);
-          m &= ~1ull;
-        }
-        const int lo = 1024 - 64 * q - limit + 1;    // lanes lo .. 63 hold bins below the limit
-        m &= lo >= 64 ? 0ull : lo <= 0 ? ~0ull : ~0ull << lo;
-        if (m) best = max(best, 1024 - 64 * q - __builtin_ctzll(m) + 1);
-      }
-      return best;
-    };
-    if (sig == 0) {
-      bw_ref = top_bin(10. * thr, 921, false);
-      if (lane == 0) xch[1] = (double)bw_ref;
+    for (int q = 0; q < 8; ++q) {
+      unsigned long long m = __ballot(or_equal ? pspec[q] >= level : pspec[q] > level);
+      const int nl = limit - 64 * q;               // lanes 0 .. nl - 1 hold bins below the limit
+      m &= nl >= 64 ? ~0ull : nl <= 0 ? 0ull : (1ull << nl) - 1ull;
+      if (m) best = max(best, 64 * q + 64 - __builtin_clzll(m));
     }
-    __syncthreads();
-    bw_ref = (int)xch[1];
-    if (sig == 1 && bw_ref > 346) bw_test = top_bin(3.16227766016838 * thr, bw_ref, true);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      unsigned long long m = __ballot(or_equal ? pspec[8 + q] >= level : pspec[8 + q] > level);
+      if (q == 0) {                                // lane 0 carries bin 512 here (spec_bin)
+        if ((m & 1ull) && 512 < limit) best = max(best, 513);
+        m &= ~1ull;
+      }
+      const int lo = 1024 - 64 * q - limit + 1;    // lanes lo .. 63 hold bins below the limit
+      m &= lo >= 64 ? 0ull : lo <= 0 ? ~0ull : ~0ull << lo;
+      if (m) best = max(best, 1024 - 64 * q - __builtin_ctzll(m) + 1);
+    }
+    return best;
+  };
+  if (!kAdvanced && sig == 1) {
+    // zero threshold = max over bins 921..1023 of the test spectrum: the mirror bins 1024 - (lane + 64 q)
+    // of q = 0 (lanes 1..63) and q = 1 (lanes 0..39); read by the reference wave behind the next barrier
+    if (lane >= 1) thr = pspec[8];
+    if (lane <= 39) thr = fmax(thr, pspec[9]);
+    thr = wave_max(thr);
+    if (lane == 0) xch[0] = thr;
   }
 
-  FE_MARK(2);                                        // bandwidths (two barriers)
+  FE_MARK(2);                                        // the test wave's zero threshold
   // ---- critical bands, internal noise, spreading ------------------------------------
   // (advanced version: of the test signal only the weighted spectrum is used -- noise in bands and EHS,
   // process_fft_block_advanced gstpeaq.c:924-959 -- so its wave goes straight to the barrier)
@@ -647,8 +639,12 @@ void frontend_kernel(FrontendArgs a) {
 
   }
   FE_MARK(6);                                        // downward spreading, excitation, record
-  __syncthreads();                                   // both spectra are in LDS
+  __syncthreads();                                   // both spectra are in LDS (and the test wave's threshold)
   FE_MARK(7);                                        // barrier
+  if (!kAdvanced && sig == 0) {
+    bw_ref = top_bin(10. * xch[0], 921, false);
+    if (lane == 0) xch[1] = (double)bw_ref;          // read by the test wave behind the next barrier
+  }
   const double* pw_ref = lds + kOffPw;
   double* pw_test = lds + kUnitDoubles + kOffPw;
   double* sa = lds + kOffScratch;                            // [512] the reference unit's scratch
@@ -669,6 +665,10 @@ void frontend_kernel(FrontendArgs a) {
   FE_MARK(8);                                        // log ratios
   __syncthreads();
   FE_MARK(9);                                        // barrier
+  if (!kAdvanced && sig == 1) {
+    bw_ref = (int)xch[1];
+    if (bw_ref > 346) bw_test = top_bin(3.16227766016838 * thr, bw_ref, true);
+  }
 
   if (sig == 1) {
     // ---- noise spectrum for the NMR MOVs (movs.c:992-996): one bin per lane and step, in place
