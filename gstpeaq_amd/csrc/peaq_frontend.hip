@@ -113,9 +113,8 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double (&p)[
   exchange16(z, unit, [&](int r) { return 16 * lane + r; }, [&](int r) { return lane + 64 * r; });
   // pass 2: radix 16, sub-transform size 16
   {
-    const int k = lane & 15;
     {
-      // twiddles W_256^(r k), r = 1..15: one table read, three squarings (r = 2, 4, 8),
+      // twiddles W_256^(r k), k = lane & 15, r = 1..15: one table read, three squarings (r = 2, 4, 8),
       // the rest as products
       // (applied as soon as they exist: only w1..w8 stay live, the register budget is 168)
       cplx w[9];
@@ -135,11 +134,31 @@ __device__ __forceinline__ void frame_power_spectrum(cplx (&z)[16], double (&p)[
       z[8] = cmul(z[8], w[8]);
     }
     dft16(z);
-    const int j = (lane - k) * 16 + k;
-    // out[j + 16 r]; pass 3 (radix 4, sub-transform size 256) reads in[lane + 64 m + 256 r'] into
-    // slot m + 4 r', i.e. slot s reads lane + 64 (s & 3) + 256 (s >> 2)
+    // out[j + 16 r] with j = 16 (lane - k) + k; pass 3 (radix 4, sub-transform size 256) wants in[lane + 64 m + 256 r']
+    // in slot m + 4 r', i.e. slot s = in[lane + 64 (s & 3) + 256 (s >> 2)].  Written out: the element of row a =
+    // lane >> 4, column k, register 4 g + p lands in row p, column k, slot 4 a + g -- the column stays, rows and
+    // registers trade places.  That is four 4 x 4 row/register transposes (one per g) on the permlane swaps and a
+    // renaming of registers: 64 vector instructions instead of 64 LDS instructions and four waits for the LDS
+    // queue (the first exchange moves data across columns and stays on LDS).
+#ifndef PEAQ_FE_LDS_EXCHANGE2
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      rows_transpose4(z[4 * g].re, z[4 * g + 1].re, z[4 * g + 2].re, z[4 * g + 3].re);
+      rows_transpose4(z[4 * g].im, z[4 * g + 1].im, z[4 * g + 2].im, z[4 * g + 3].im);
+    }
+#pragma unroll
+    for (int a2 = 0; a2 < 4; ++a2)                   // slot 4 a + g <- register 4 g + a
+#pragma unroll
+      for (int g = a2 + 1; g < 4; ++g) {
+        const cplx t = z[4 * a2 + g];
+        z[4 * a2 + g] = z[4 * g + a2];
+        z[4 * g + a2] = t;
+      }
+#else
+    const int k = lane & 15, j = (lane - k) * 16 + k;
     exchange16(z, unit, [&](int r) { return j + 16 * r; },
                [&](int s) { return lane + 64 * (s & 3) + 256 * (s >> 2); });
+#endif
   }
   {
     // W_1024^(r i), i = lane + 64 m: W_1024^lane from the table, times W_16^m (constants), squared and cubed
@@ -814,10 +833,12 @@ void frontend_kernel(FrontendArgs a) {
         const int p = 1 << (2 * pass);
         const int k = lane & (p - 1);
         if (pass > 0) {
+          if (pass < 3) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const double2 x = xb[lane + 64 * r];
-            w[r] = {x.x, x.y};
+            for (int r = 0; r < 4; ++r) {
+              const double2 x = xb[lane + 64 * r];
+              w[r] = {x.x, x.y};
+            }
           }
           // W_{4p}^(r k): W_16^(lane & 3), W_64^(lane & 15), W_256^lane from the table, squared and cubed
           const cplx t1 = tw_lane(ct, 4 + pass, lane), t2 = csqr(t1), t3 = cmul(t2, t1);
@@ -826,12 +847,17 @@ void frontend_kernel(FrontendArgs a) {
           w[3] = cmul(w[3], t3);
         }
         dft4(w[0], w[1], w[2], w[3]);
-        if (pass < 3) {
+        if (pass < 2) {
           const int j = (lane - k) * 4 + k;
           wave_lds_fence();
 #pragma unroll
           for (int r = 0; r < 4; ++r) xb[j + r * p] = make_double2(w[r].re, w[r].im);
           wave_lds_fence();
+        } else if (pass == 2) {
+          // out[64 (lane >> 4) + (lane & 15) + 16 r], read back as in[lane + 64 r']: row and register trade
+          // places, the column stays -- a row/register transpose on the permlane swaps, no LDS
+          rows_transpose4(w[0].re, w[1].re, w[2].re, w[3].re);
+          rows_transpose4(w[0].im, w[1].im, w[2].im, w[3].im);
         }
       }
     };

@@ -106,6 +106,35 @@ __device__ __forceinline__ void swap_halves_i(int v, int& a, int& b) {
     b = (int)r[1];
   }
 }
+// 4 x 4 transpose between the four rows (16 lanes each) of a wave and four registers: on return x[a] holds in
+// row p what x[p] held in row a.  v_permlane32_swap exchanges the upper two rows of its first operand with the
+// lower two of its second, v_permlane16_swap the odd rows of the first with the even rows of the second: two of
+// each per 32-bit register quadruple, no LDS.
+__device__ __forceinline__ void rows_transpose4_u(unsigned& x0, unsigned& x1, unsigned& x2, unsigned& x3) {
+  auto r = __builtin_amdgcn_permlane32_swap(x0, x2, false, false);
+  x0 = r[0];
+  x2 = r[1];
+  r = __builtin_amdgcn_permlane32_swap(x1, x3, false, false);
+  x1 = r[0];
+  x3 = r[1];
+  r = __builtin_amdgcn_permlane16_swap(x0, x1, false, false);
+  x0 = r[0];
+  x1 = r[1];
+  r = __builtin_amdgcn_permlane16_swap(x2, x3, false, false);
+  x2 = r[0];
+  x3 = r[1];
+}
+__device__ __forceinline__ void rows_transpose4(double& x0, double& x1, double& x2, double& x3) {
+  unsigned l0 = __double2loint(x0), l1 = __double2loint(x1), l2 = __double2loint(x2), l3 = __double2loint(x3);
+  unsigned h0 = __double2hiint(x0), h1 = __double2hiint(x1), h2 = __double2hiint(x2), h3 = __double2hiint(x3);
+  rows_transpose4_u(l0, l1, l2, l3);
+  rows_transpose4_u(h0, h1, h2, h3);
+  x0 = __hiloint2double(h0, l0);
+  x1 = __hiloint2double(h1, l1);
+  x2 = __hiloint2double(h2, l2);
+  x3 = __hiloint2double(h3, l3);
+}
+
 template <bool ROWS16>
 __device__ __forceinline__ void swap_halves_d(double v, double& a, double& b) {
   int alo, blo, ahi, bhi;
