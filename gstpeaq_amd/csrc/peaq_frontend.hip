@@ -223,9 +223,18 @@ __device__ __forceinline__ int spec_bin(int s, int lane) {
 // fetched eight at a time, so that a band of 25 bins costs four LDS round trips instead of 25; beyond
 // the band the lane reads sp[zero] -- a slot the caller has set to 0 -- so that the sum needs no
 // second predicate (adding +0 is exact); the order of the additions is that of the plain loop.
-__device__ __forceinline__ double group_band(const BandTables* __restrict__ bt, int b, const double* sp, int zero) {
-  const int lo = bt->lo[b], hi = bt->hi[b];
-  double p = bt->wlo[b] * sp[lo] + bt->whi[b] * sp[hi];
+struct BandEdge {                                    // one band's row of the grouping tables (fftearmodel.c:730-760)
+  int lo, hi;
+  double wlo, whi;
+};
+// Requested well before the band sum that uses it: the four values come through L2 with a different band per lane,
+// and a band sum that starts by waiting for them waits the longest part of its own duration.
+__device__ __forceinline__ BandEdge load_band_edge(const BandTables* __restrict__ bt, int b) {
+  return {bt->lo[b], bt->hi[b], bt->wlo[b], bt->whi[b]};
+}
+__device__ __forceinline__ double group_band(const BandEdge& e, const double* sp, int zero) {
+  const int lo = e.lo, hi = e.hi;
+  double p = e.wlo * sp[lo] + e.whi * sp[hi];
   for (int k0 = lo + 1; k0 < hi; k0 += 8) {
     typedef const __attribute__((address_space(3))) double* lds_cptr;
     const lds_cptr q = (lds_cptr)sp + k0, z = (lds_cptr)sp + zero;
@@ -373,6 +382,7 @@ void frontend_kernel(FrontendArgs a) {
   const unsigned item = xcd_remap(blockIdx.x, gridDim.x);
   unsigned pair, fl;
   const int chan = decode(item, pair, fl);
+  FE_MARK(15);                                       // wave start-up: first instructions, kernel arguments
   const unsigned n_ref = a.n_ref ? a.n_ref[pair] : a.n_uniform_ref;
   const unsigned n_test = a.n_test ? a.n_test[pair] : a.n_uniform_test;
   unsigned frame, frame_origin;
@@ -512,6 +522,9 @@ void frontend_kernel(FrontendArgs a) {
   double pspec[16];                                  // unweighted power spectrum, bin lane + 64 q
   frame_power_spectrum(z, pspec, unit, lane, ct, a.level_factor);
 
+  // the band edges of this lane's two band sums (a narrow and a wide band, see below), requested now
+  const int gb1 = lane < (NB + 1) / 2 ? lane : 0, gb2 = lane < (NB + 1) / 2 ? NB - 1 - lane : 0;
+  const BandEdge edge1 = load_band_edge(bt, gb1), edge2 = load_band_edge(bt, gb2);
   // The logarithm table (log_tab, peaq_wave.h) into LDS: every wave fills its OWN copy -- no workgroup barrier
   // stands between the transform and the first logarithm any more -- and does so here, where its registers have
   // just become free (at the start of the kernel the three loads would sit in front of the frame's own).
@@ -589,30 +602,39 @@ void frontend_kernel(FrontendArgs a) {
     // the longest loop is ~27 bins instead of the ~50 of two adjacent top bands -- handed over to
     // the two-adjacent-bands layout of everything that follows through LDS.
     double* ppx = scratch + 256;                       // [NB]
+    // ... and the per-band constants of the spreading phase, requested before the band sums run
+    const int b0 = 2 * lane;
+    double c_noise[2], c_lnauc[2], c_gil[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int b = b0 + s2 < NB ? b0 + s2 : 0;
+      c_noise[s2] = bt->internal_noise[b];
+      c_lnauc[s2] = bt->ln_aUC[b];
+      c_gil[s2] = bt->gIL[b];
+    }
     if (lane < (NB + 1) / 2) {
       const int b1 = lane, b2 = NB - 1 - lane;
-      ppx[b1] = group_band(bt, b1, pw, kZeroSlot);
-      if (b2 != b1) ppx[b2] = group_band(bt, b2, pw, kZeroSlot);
+      ppx[b1] = group_band(edge1, pw, kZeroSlot);
+      if (b2 != b1) ppx[b2] = group_band(edge2, pw, kZeroSlot);
     }
     wave_lds_fence();
     FE_MARK(3);                                        // band grouping
     double ene[2], ae[2];
-    const int b0 = 2 * lane;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int b = b0 + s;
       if (b < NB) {
-        const double pp = ppx[b] + bt->internal_noise[b];                                            // :483-485
+        const double pp = ppx[b] + c_noise[s];                                                       // :483-485
         // Kabal (23)-(24); fftearmodel.c:649-656.  a^y evaluated as exp(y ln a); the three powers of
         // aUCE share one exponential (t = aUCE^0.2: aUCE^0.4 = t^2, aUCE = t^5), and En^0.4 takes its
         // logarithm as ln Pp - ln(gIL + gIU - 1) instead of dividing first
         const double ln_pp = FE_LOG(pp, ltab);
-        const double ln_a = bt->ln_aUC[b] + bt->dz02 * ln_pp;
+        const double ln_a = c_lnauc[s] + bt->dz02 * ln_pp;
         const double t = exp_fast(0.2 * ln_a), t2 = t * t;
         const double a_uce = t2 * t2 * t;
         const double g_iu = div_fast(1. - exp_fast((double)(NB - b) * ln_a), 1. - a_uce);
         ae[s] = t2;
-        ene[s] = exp_fast(0.4 * (ln_pp - FE_LOG(bt->gIL[b] + g_iu - 1., ltab)));
+        ene[s] = exp_fast(0.4 * (ln_pp - FE_LOG(c_gil[s] + g_iu - 1., ltab)));
       } else {
         ae[s] = 0.;
         ene[s] = 0.;
@@ -711,8 +733,8 @@ void frontend_kernel(FrontendArgs a) {
     wave_lds_fence();
     if (lane < (NB + 1) / 2) {                        // balanced assignment as above, straight to the record
       const int b1 = lane, b2 = NB - 1 - lane;
-      rec[kRecNoise + b1] = group_band(bt, b1, pw_test, kOffPw - kUnitDoubles);
-      if (b2 != b1) rec[kRecNoise + b2] = group_band(bt, b2, pw_test, kOffPw - kUnitDoubles);
+      rec[kRecNoise + b1] = group_band(edge1, pw_test, kOffPw - kUnitDoubles);
+      if (b2 != b1) rec[kRecNoise + b2] = group_band(edge2, pw_test, kOffPw - kUnitDoubles);
     } else if (lane < (NB + 1) / 2 + kBandStride - NB) {
       rec[kRecNoise + NB + lane - (NB + 1) / 2] = 0.;  // padding slots of the band vector
     }

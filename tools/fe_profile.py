@@ -13,10 +13,10 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch  # noqa: E402,F401
 import gstpeaq_amd  # noqa: E402
 
-PHASES = ["reductions+flags (after the loads)", "FFT+split", "bandwidths (2 barriers)", "band grouping", "log/exp per band",
+PHASES = ["reductions+flags (after the loads)", "FFT+split", "zero threshold of the bandwidth search", "band grouping", "log/exp per band",
           "upward spreading", "downward+excitation+store", "barrier", "log ratios", "barrier",
           "ref: FFT-512 | test: noise+grouping", "ref: product+inverse", "ref: normalise+FFT-256+peak",
-          "work-item decoding", "sample loads + window", "-"]
+          "work-item decoding (after start-up)", "sample loads + window", "wave start-up + kernel arguments"]
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 ctx = gstpeaq_amd.Context(0)
 ref, test = gstpeaq_amd.synth_fill(ctx, 1, pairs, 2, 480000)
