@@ -48,7 +48,10 @@ namespace peaq {
 // LDS per wave ("unit"): 1288 doubles = 10304 B.  During the FFT the first 1088 doubles are the
 // exchange buffer (one real component of the 1024 complex points at a time, padded); afterwards
 // Pw[0..775] (weighted power spectrum) followed by 512 doubles of scratch.
-constexpr int kPrefetchItems = 64;            // L2 prefetch distance in work items (see the kernel)
+#ifndef PEAQ_FE_PREFETCH_ITEMS
+#define PEAQ_FE_PREFETCH_ITEMS 64
+#endif
+constexpr int kPrefetchItems = PEAQ_FE_PREFETCH_ITEMS;            // L2 prefetch distance in work items (see the kernel)
 constexpr int kUnitDoubles = 1288;
 constexpr int kOffPw = 0;                     // Pw[776]
 constexpr int kOffScratch = 776;              // 512 doubles
