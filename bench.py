@@ -177,13 +177,19 @@ def result_deltas(gpu_rows, cpu, advanced):
 
 # ----------------------------------------------------------------------------------------------
 def source_hash():
-    """sha256 over the kernel sources (gstpeaq_amd/csrc/*): what the counter profiles are valid for"""
+    """sha256 over the kernel sources (gstpeaq_amd/csrc/*) with comments and white space taken out: what the
+    counter profiles are valid for (a reworded comment does not make a profile stale, a changed statement does)"""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in sorted((ROOT / "gstpeaq_amd" / "csrc").glob("*")):
         if f.is_file():
+            text = f.read_text(errors="replace")
+            if f.suffix in (".hip", ".h", ".cpp"):
+                text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+                text = re.sub(r"//[^\n]*", "", text)
             h.update(f.name.encode())
-            h.update(f.read_bytes())
+            h.update("".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

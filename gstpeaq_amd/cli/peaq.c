@@ -13,11 +13,13 @@
  * audioconvert does (S16 -> x/32768, verified in SURVEY.md 8(c)).  The ear
  * models are defined for 48 kHz only (earmodel.c:43): files at another rate are
  * converted first, as the reference's `audioresample` does -- here with a
- * Kaiser-windowed sinc interpolator (64 zero crossings, stop band below -120 dB,
- * cutoff at 0.96 of the lower Nyquist frequency).  The two resamplers are
- * different filters, so for such files ODG/DI agree with the reference only to
- * a few 1e-3, not digit for digit (48 kHz files: digit for digit); pass
- * --no-resample to refuse them instead.
+ * Kaiser-windowed sinc interpolator whose parameters are the measured ones of
+ * that `audioresample` (resample_to_48k below).  Against the real reference
+ * chain ODG/DI agree to 6e-5 in seven of eight pinned cases and 2.3e-3 in the
+ * eighth (tests/test_cli_resampler.py; stated tolerance 5e-3).  48 kHz files:
+ * digit for digit in the basic version and with PEAQ_AMD_FIR=f64; the advanced
+ * version's default arithmetic is held to 1e-6 in ODG/DI (include/peaq_amd.h,
+ * PEAQ_FIR_F16X3).  --no-resample refuses files at other rates instead.
  */
 #include <math.h>
 #include <stdint.h>

@@ -317,11 +317,11 @@ struct MfmaH3 {
   static __device__ __forceinline__ int row(int kk, int i) { return 4 * kk + i; }
 };
 
-// FP32 variant: the mixed-precision ledger (tools/precision_ledger.py, profiles/r02_precision_ledger.json)
-// prices it at max |dODG| = 5e-8 over 39 advanced cases -- the FIR outputs only enter the model as
-// |A|^2 in 40 bands after spreading and masking -- for twice the matrix rate, half the LDS traffic of the
-// window and FP32 operand construction.  The engine therefore runs it by default; peaq_ctx_set_fir_fp64()
-// or PEAQ_AMD_FIR_FP64=1 selects the FP64 instruction (the stage tests hold THAT to 1e-9 of the oracle).
+// FP32 variant (PEAQ_FIR_F32, selectable): the mixed-precision ledger (tools/precision_ledger.py,
+// profiles/r02_precision_ledger.json) prices it at max |dODG| = 5e-8 over 39 advanced cases -- the FIR outputs
+// only enter the model as |A|^2 in 40 bands after spreading and masking.  The engine's default is the split-FP16
+// form below (fir_mfma_h3); peaq_ctx_set_fir_mode() / PEAQ_AMD_FIR select this one or the FP64 instruction
+// (the arithmetic the stage tests hold to 1e-9 of the oracle).
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Adds the accumulator tiles of one run of K steps into A (LDS atomics; A was zeroed in phase 0).
