@@ -361,6 +361,9 @@ __attribute__((amdgpu_num_vgpr(PEAQ_FE_NUM_VGPR)))
 #endif
 void frontend_kernel(FrontendArgs a) {
   extern __shared__ double lds[];
+  // a fresh wave gets its frame requested before its older neighbours on the SIMD issue their next arithmetic:
+  // what it waits for longest is that frame (+ 0.5 % measured; back to normal once the loads are out)
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63;
   // 0 = reference wave, 1 = test wave; wave-uniform, so keep it (and all that hangs on it) scalar
   const int sig = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -485,6 +488,7 @@ void frontend_kernel(FrontendArgs a) {
     }
   }
 
+  __builtin_amdgcn_s_setprio(0);
 #ifdef PEAQ_FE_PROFILE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
