@@ -900,29 +900,29 @@ void frontend_kernel(FrontendArgs a) {
       constexpr double kScale = 1. / 2048.;
       cb[lane] = make_double2(v[0].re * kScale, -v[0].im * kScale);
       cb[lane + 64] = make_double2(v[1].re * kScale, -v[1].im * kScale);
+      // ... and in the same round trip the running window energy WITHOUT its start value d0 = c[0] (which only
+      // exists once the correlation has been read back): dk[l] - d0 = sum_{j<l} (d[j+256]^2 - d[j]^2), l = 4 lane + t
+      double run = run_in;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sa[4 * lane + t] = run;
+        run += g[t];
+      }
     }
     wave_lds_fence();
     FE_MARK(11);                                     // reference wave: product + inverse transform
     // ---- part 3 (movs.c:1393-1441): lane owns lags lane + 64 m ------------------------------------------
-    double* d = sa;
-    double c[4];
+    double c[4], dk[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) c[m] = sb[lane + 64 * m];
-    const double d0 = read_lane<0>(c[0]);
-    {
-      wave_lds_fence();
-      double run = d0 + run_in;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        d[4 * lane + t] = run;                       // dk[l], l = 4 lane + t
-        run += g[t];
-      }
-      wave_lds_fence();
+    for (int m = 0; m < 4; ++m) {
+      c[m] = sb[lane + 64 * m];
+      dk[m] = sa[lane + 64 * m];
     }
+    const double d0 = read_lane<0>(c[0]);
     double cavg = 0.;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      c[m] *= rsqrt_pos(d0 * d[lane + 64 * m]);      // NaN when d0 = 0 (identical signals), as in the reference
+      c[m] *= rsqrt_pos(d0 * (d0 + dk[m]));          // NaN when d0 = 0 (identical signals), as in the reference
       cavg += c[m];
     }
     // the mean is removed before the window (the shipped EHS_SUBTRACT_DC_BEFORE_WINDOW, movs.c:1409-1421) or
