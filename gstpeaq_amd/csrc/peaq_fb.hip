@@ -267,6 +267,7 @@ struct BankLds {
   double ex[kFbBands][kTileBlocks];                 // excitation per (band, block) on its way to the records
   double hist[kFbBands][10];       // the 10 newest E0 values of the previous tile, oldest first
   double cu[kFbBands];
+  double c0[kFbBands];             // ln DIST (24 + 230 / fc): constant of the slope exponent, per band
 };
 
 // A plain ds_read_b64 moves 256 B/clk/CU, the merged ds_read2_b64 the compiler likes to form
@@ -758,9 +759,17 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
   const double kM1 = sm, kM2 = kM1 * kM1, kM4 = kM2 * kM2, kM8 = kM4 * kM4, kM16 = kM8 * kM8;
 
   constexpr double kC1 = -2. * kLnDist / 2.302585092994046;         // -0.2 * 10 / ln 10 * ln DIST
-  double c0[10];
+  // ln DIST (24 + 230 / fc) of the wave's ten bands: in registers for the reduced-precision engine (its kernel has
+  // them to spare and is 4 % slower reading them from LDS), in LDS for the FP64 engines, whose FIR loops leave
+  // none (the FP64 kernel spilled 20 registers with them, 10 -- outside the tile loop -- without: 2 % on its time)
+  constexpr bool kC0InRegs = sizeof(WT) == 2;
+  double c0r[kC0InRegs ? 10 : 1];
+  if constexpr (kC0InRegs) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) c0[i] = kLnDist * (24. + 230. / bt->fc[wave_band(wv, i)]);
+    for (int i = 0; i < 10; ++i) c0r[i] = kLnDist * (24. + 230. / bt->fc[wave_band(wv, i)]);
+  } else if (tid < kFbBands) {
+    sh.c0[tid] = kLnDist * (24. + 230. / bt->fc[tid]);
+  }
 
   constexpr int kKeep = kWin - kTileSub * 32;                       // 1425 samples shared by consecutive tiles
   constexpr int kPre = (kWin - kKeep + 255) / 256;                  // new samples per thread (8)
@@ -865,7 +874,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         // mantissa in FP64, so that the tiny energies of silent bands do not underflow
         const double p = re[i] * re[i] + im[i] * im[i];
         const float l2 = (float)__builtin_amdgcn_frexp_exp(p) + __builtin_amdgcn_logf((float)__builtin_amdgcn_frexp_mant(p));
-        const float ex = fminf((float)(4. * kLnDist / kLn2), fmaf((float)kC1, l2, (float)(c0[i] * (1. / kLn2))));
+        const float ex = fminf((float)(4. * kLnDist / kLn2), fmaf((float)kC1, l2, (float)(c0r[i] * (1. / kLn2))));
         const float dist_s = __builtin_amdgcn_exp2f(p == 0. ? -__builtin_inff() : ex);
         // The slope filter itself runs in FP64 like the reference's: it is the one recurrence ALONG the stream in
         // this phase, and in FP32 its rounding depended on where a launch (hence a tile) happened to start -- a
@@ -873,7 +882,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         const double v = wave_prefix_geometric(sg * (double)dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
         cu = fma(decay, sh.cu[b], v);
       } else {
-        const double dist_s = exp_fast(fmin(4. * kLnDist, c0[i] + kC1 * log_nonneg(re[i] * re[i] + im[i] * im[i])));
+        const double dist_s = exp_fast(fmin(4. * kLnDist, sh.c0[b] + kC1 * log_nonneg(re[i] * re[i] + im[i] * im[i])));
         const double v = wave_prefix_geometric(sg * dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
         cu = v + decay * sh.cu[b];
       }
