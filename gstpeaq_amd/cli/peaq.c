@@ -17,9 +17,10 @@
  * that `audioresample` (resample_to_48k below).  Against the real reference
  * chain ODG/DI agree to 6e-5 in seven of eight pinned cases and 2.3e-3 in the
  * eighth (tests/test_cli_resampler.py; stated tolerance 5e-3).  48 kHz files:
- * digit for digit in the basic version and with PEAQ_AMD_FIR=f64; the advanced
- * version's default arithmetic is held to 1e-6 in ODG/DI (include/peaq_amd.h,
- * PEAQ_FIR_F16X3).  --no-resample refuses files at other rates instead.
+ * digit for digit in both versions -- this tool runs the advanced version's
+ * filter bank in FP64 like the reference; PEAQ_AMD_FIR=f16x3 selects the
+ * engine's reduced-precision bank (held to 1e-6 in ODG/DI, include/peaq_amd.h).
+ * --no-resample refuses files at other rates instead.
  */
 #include <math.h>
 #include <stdint.h>
@@ -338,6 +339,13 @@ main (int argc, char **argv)
   }
   if (peaq_ctx_create (getenv ("PEAQ_AMD_DEVICE") ? atoi (getenv ("PEAQ_AMD_DEVICE")) : 0, &ctx) != PEAQ_OK) {
     printf ("Error: peaq engine could not be instantiated - %s\n", peaq_last_error ());
+    return 2;
+  }
+  /* One file pair is not a throughput job: the advanced version's filter bank runs in the reference's own
+   * arithmetic (all FP64) here, the engine's faster reduced-precision bank only on request (PEAQ_AMD_FIR). */
+  if (advanced && !getenv ("PEAQ_AMD_FIR") && !getenv ("PEAQ_AMD_FIR_FP64")
+      && peaq_ctx_set_fir_mode (ctx, PEAQ_FIR_F64) != PEAQ_OK) {
+    printf ("Error: %s\n", peaq_last_error ());
     return 2;
   }
   if (!getenv ("PEAQ_AMD_CLI_STREAM")) {
