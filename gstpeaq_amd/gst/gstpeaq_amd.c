@@ -82,6 +82,14 @@ shared_context (void)
     if (peaq_ctx_create (dev ? atoi (dev) : 0, &ctx) != PEAQ_OK) {
       GST_ERROR ("libpeaq_amd: %s", peaq_last_error ());
       ctx = NULL;
+    } else {
+      /* A pipeline with its own session per element is not a throughput job: the advanced version's filter
+       * bank runs in the reference's arithmetic (all FP64).  A process that batches its elements through the
+       * broker keeps the engine's default, the faster reduced-precision bank; PEAQ_AMD_FIR overrides both. */
+      const gchar *max = g_getenv ("PEAQ_AMD_BROKER");
+      if (!(max && atoi (max) > 0) && !g_getenv ("PEAQ_AMD_FIR") && !g_getenv ("PEAQ_AMD_FIR_FP64")
+          && peaq_ctx_set_fir_mode (ctx, PEAQ_FIR_F64) != PEAQ_OK)
+        GST_WARNING ("libpeaq_amd: %s", peaq_last_error ());
     }
     g_once_init_leave (&once, 1);
   }
