@@ -4,6 +4,8 @@ files committed under profiles/.
 
   tools/rocprof_summary.py stats  DB              -> per-kernel calls / total / average (like --stats)
   tools/rocprof_summary.py pmc    DB [DB ...]     -> per-kernel average of every collected counter
+  tools/rocprof_summary.py timeline DB [N]        -> the last N kernel dispatches in start order: name, queue, start and
+                                                     end in ms after the first of them
 """
 import json
 import sqlite3
@@ -40,9 +42,22 @@ def pmc(dbs):
     return out
 
 
+def timeline(db, n):
+    cur = sqlite3.connect(db).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+    q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+    rows = cur.execute(f"select name, {q}, start, end from kernels order by start").fetchall()[-n:]
+    t0 = rows[0][2]
+    return [dict(kernel=short(k)[:60], queue=qq, start_ms=round((a - t0) / 1e6, 3), end_ms=round((b - t0) / 1e6, 3),
+                 ms=round((b - a) / 1e6, 3)) for k, qq, a, b in rows]
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
-    if mode == "stats":
+    if mode == "timeline":
+        for r in timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 40):
+            print("%-62s q%-3s %9.3f .. %9.3f  (%8.3f ms)" % (r["kernel"], r["queue"], r["start_ms"], r["end_ms"], r["ms"]))
+    elif mode == "stats":
         print(json.dumps(stats(sys.argv[2]), indent=1))
     else:
         print(json.dumps(pmc(sys.argv[2:]), indent=1))
