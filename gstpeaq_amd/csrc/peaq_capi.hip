@@ -56,6 +56,8 @@ static int fail(int code, const std::string& msg) {
 
 extern "C" const char* peaq_last_error(void) { return g_err.c_str(); }
 extern "C" const char* peaq_version(void) { return "0.1.0 gfx950"; }
+// host only, no device: the filter-bank tables of the FP64 engine against the reference's plain sums (peaq_tables.cpp)
+extern "C" double peaq_debug_fb_tables_selfcheck(void) { return peaq::fb_tables_selfcheck(); }
 
 // ---------------------------------------------------------------------------
 // framing arithmetic

@@ -43,6 +43,22 @@ constexpr int kHfD1[kMfTiles]     = {1, 465, 673};
 constexpr int kHfD2[kMfTiles]     = {2, 466, 674};
 constexpr int kHfTotalBlocks = 34;
 enum { HF_RE_HI_1, HF_RE_LO_1, HF_IM_HI_1, HF_IM_LO_1, HF_RE_HI_2, HF_RE_LO_2, HF_NIM_HI_2, HF_NIM_LO_2, HF_OPERANDS };
+// The FP64 engine's bank (peaq_fb.hip, "block-sum form"): the Hann window of a filter is three rectangular
+// windows, 4/N cos^2(pi m/N) e^(-j w m) = sum_i g_i e^(-j w_i m) with w_i = w, w + 2 pi/N, w - 2 pi/N, so the
+// part of a filter's window that consists of WHOLE 32-sample blocks of the signal is, per exponential, a
+// running sum along the outputs (one every 32 samples): V(t) = e^(j 32 w_i) V(t-1) + enter(t) - leave(t), where
+// enter / leave are dot products of ONE block with a fixed row of 32 coefficients.  Only the two blocks the
+// window's ends fall into need the filter's own coefficients.  Per band and output that is 16 rows of 32
+// multiply-adds (6 enter, 6 leave, 2 + 2 edge) whatever the filter's length, against N for the direct form:
+// the bands 0 .. kBsBands-1 (N >= 262) run this way, two bands per 16-row tile of the matrix instruction,
+// the rest as one direct (folded) GEMM tile like before.
+constexpr int kBsBands  = 24;
+constexpr int kBsPairs  = kBsBands / 2;
+constexpr int kBsChains = kBsBands * 3;
+// the direct tile: bands 24 .. 39, delays kMfdD0 .. 729 in kMfdSteps K steps of four
+constexpr int kMfdBand0 = 24;
+constexpr int kMfdD0    = 611;
+constexpr int kMfdSteps = 30;
 
 // ---- constant tables (built on the host in FP64, peaq_tables.cpp) ----------
 struct CommonTables {
@@ -121,6 +137,21 @@ struct FbTables {               // fbearmodel.c:57-61,182-225
   // kHfD2 + 32 s + 8 kg + e (X2), e = 0..7, scaled by 2^hf_exp[band] -- and the factor that undoes that scale
   unsigned short hf[kHfTotalBlocks][HF_OPERANDS][64][8];
   double hf_unscale[kMfTiles * 16];     // 2^-hf_exp per band row (0 for the rows beyond band 39)
+  // ---- block-sum form (kBs* above).  Window columns are blocks of 32 samples (column c = samples 32 c .. 32 c + 31
+  // of the kernel's window, whose sample 727 + 32 t is the centre of every filter at output t).  Band b's window at
+  // t = 0 is [728 - N/2, 726 + N/2]: cL = first column it touches, cR = last; columns cL+1 .. cR-1 are whole.
+  int    bs_col_head[kBsPairs];         // first column of the pair's head tile at t = 0: min(cR) - 1
+  int    bs_col_tail[kBsPairs];         // ... of its tail tile: min(cL)
+  int    bs_off_enter[kBsBands];        // column of band b's enter rows at output t: bs_col_head + t + this (edge rows: + 1)
+  int    bs_off_leave[kBsBands];        // column of its leave and left-edge rows:     bs_col_tail + t + this
+  int    bs_whole[kBsBands];            // J = cR - 1 - cL whole columns
+  // A operands: [pair][head, tail][K step][lane = row + 16 (k mod 4)], row = 8 (band in pair) + type,
+  // type 0..5 = re, im of the three exponentials (head: enter, tail: MINUS leave), 6, 7 = re, im of the edge block
+  double bs_coef[kBsPairs][2][8][64];
+  double bs_rot[kBsChains][5][2];       // chain = 3 band + i: e^(j 32 w_i k), k = 1, 2, 4, 8, 16 (re, im)
+  double bs_pow[kBsChains][16][2];      // e^(j 32 w_i (l + 1)), l = 0..15
+  double mfd_re[kMfdSteps * 64];        // the direct tile's A operands, lane = band - 24 + 16 (d - kMfdD0 - 4 s)
+  double mfd_im[kMfdSteps * 64];
 };
 
 // ---- per-frame record: front end -> back end --------------------------------

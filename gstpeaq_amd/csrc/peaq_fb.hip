@@ -24,6 +24,9 @@
 #include "peaq_kernels.h"
 #include "peaq_wave.h"
 #include <type_traits>
+#ifdef PEAQ_DEV_PROBES                               // VARIANT builds only (csrc/Makefile): never in the product library
+#include "dev_probes.inc"
+#endif
 
 namespace peaq {
 
@@ -258,6 +261,12 @@ struct Window<_Float16> {
 
 template <typename WT>
 struct BankLds {
+  // (the window is not the first member: the run-in of the block-sum form, bs_pair below, reads up to 39 columns
+  // in front of it -- values it then discards -- and those addresses must stay inside the allocation)
+  double hist[kFbBands][10];       // the 10 newest E0 values of the previous tile, oldest first
+  double cu[kFbBands];
+  double c0[kFbBands];             // ln DIST (24 + 230 / fc): constant of the slope exponent, per band
+  double vst[kBsChains][2];        // FP64 engine: the running sums V of the block-sum form after the previous tile
   Window<WT> win;                                   // phase 1: the filtered signal
   struct {
     double re[kFbBands][kACols];                    // A[band][time]: GEMM result, then phases 2..4 in place
@@ -265,9 +274,6 @@ struct BankLds {
   } a;
   double e1[kFbBands][kTileBlocks];
   double ex[kFbBands][kTileBlocks];                 // excitation per (band, block) on its way to the records
-  double hist[kFbBands][10];       // the 10 newest E0 values of the previous tile, oldest first
-  double cu[kFbBands];
-  double c0[kFbBands];             // ln DIST (24 + 230 / fc): constant of the slope exponent, per band
 };
 
 // A plain ds_read_b64 moves 256 B/clk/CU, the merged ds_read2_b64 the compiler likes to form
@@ -356,91 +362,240 @@ struct FirSeg {
   }
 };
 
+// The direct (folded) form for the FP64 engine's short filters: ONE row tile, bands 24 .. 39 (peaq_device.h kMfd*),
+// its 30 K steps cut into four runs (8 + 8 + 7 + 7), one per wave; every run leaves a partial sum that is added
+// into A with LDS atomics (rows 24 .. 39 are zeroed before).  Operands as described above: per K step two
+// coalesced coefficient reads (all of a run's are requested up front) and eight window reads one step ahead.
 template <typename M>
-__device__ __forceinline__ void fir_mfma(BankLds<typename M::T>& sh, const typename M::T* __restrict__ mf_re,
-                                         const typename M::T* __restrict__ mf_im, int wv, int lane) {
+__device__ __forceinline__ void fir_mfma_tail(BankLds<typename M::T>& sh, const typename M::T* __restrict__ mf_re,
+                                              const typename M::T* __restrict__ mf_im, int wv, int lane) {
   typedef typename M::T T;
   typedef typename M::Acc Acc;
+  static_assert(8 + 8 + 7 + 7 == kMfdSteps, "split of the K steps over the four waves");
   const int j = lane & 15, kk = lane >> 4;
-  // K steps [g, g_end) of this wave: 66 + 65 + 65 + 65
-  int g = wv == 0 ? 0 : 1 + 65 * wv;
-  const int g_end = 66 + 65 * wv;
-  static_assert(66 + 65 * 3 == kMfTotalSteps, "split of the K steps over the four waves");
-  while (g < g_end) {
-    const FirSeg sg(g, g_end);
-    const int n = sg.n;
-    const Acc zero = {0, 0, 0, 0};
-    Acc ar0 = zero, ar1 = zero, ar2 = zero, ar3 = zero, ai0 = zero, ai1 = zero, ai2 = zero, ai3 = zero;
-    const T* __restrict__ cr = mf_re + (size_t)g * 64 + lane;
-    const T* __restrict__ ci = mf_im + (size_t)g * 64 + lane;
-    const int d = sg.d0 + 4 * sg.s0 + kk;            // this lane's delay in the first K step
-    int u1 = kFbRing - d;                            // window coordinate of x[-d] at t = 0 ...
-    int u2 = d - 2;                                  // ... and of its mirror x[-(1458 - d)]
-    // the B operands of a K step are read from LDS one step ahead of their use, so that the eight
-    // MFMAs of the step before cover the LDS latency (the read past the end of a run is harmless: the
-    // window has 1456 + 59 * 32 samples, the delays stay below 736)
-    T bx[4], by[4];
-    auto fetch = [&](T (&x)[4], T (&y)[4]) {
-      const T* p1 = sh.win.v + win_off(u1) + j;        // time points j, 16 + j, 32 + j, 48 + j
-      const T* p2 = sh.win.v + win_off(u2) + j;
+  const int g = wv < 2 ? 8 * wv : 16 + 7 * (wv - 2);
+  const int n = wv < 2 ? 8 : 7;
+  const Acc zero = {0, 0, 0, 0};
+  Acc ar0 = zero, ar1 = zero, ar2 = zero, ar3 = zero, ai0 = zero, ai1 = zero, ai2 = zero, ai3 = zero;
+  // (the addresses are hidden from the compiler: the coefficients are the same in every tile, and hoisted out of
+  // the tile loop their 32 registers -- with the other phases' -- end up in scratch)
+  const T* cr = mf_re + (size_t)g * 64 + lane;
+  const T* ci = mf_im + (size_t)g * 64 + lane;
+  asm volatile("" : "+v"(cr), "+v"(ci));
+  T hr[8], hi[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        x[q] = lds_rd(p1 + 16 * q);
-        y[q] = lds_rd(p2 + 16 * q);
-      }
-    };
-    fetch(bx, by);
-    auto step = [&](T hr, T hi) {
+  for (int q = 0; q < 8; ++q) {
+    const int qq = q < n ? q : n - 1;                // (wave-uniform; the eighth load of a seven-step run repeats the seventh)
+    hr[q] = cr[64 * qq];
+    hi[q] = ci[64 * qq];
+  }
+  const int d = kMfdD0 + 4 * g + kk;                 // this lane's delay in the first K step
+  int u1 = kFbRing - d;                              // window coordinate of x[-d] at t = 0 ...
+  int u2 = d - 2;                                    // ... and of its mirror x[-(1458 - d)]
+  T bx[4], by[4];
+  auto fetch = [&](T (&x)[4], T (&y)[4]) {
+    const T* p1 = sh.win.v + win_off(u1) + j;        // time points j, 16 + j, 32 + j, 48 + j
+    const T* p2 = sh.win.v + win_off(u2) + j;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      x[q] = lds_rd(p1 + 16 * q);
+      y[q] = lds_rd(p2 + 16 * q);
+    }
+  };
+  fetch(bx, by);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (s < n) {
       T nx[4], ny[4];
       u1 -= 4;
       u2 += 4;
-      fetch(nx, ny);
+      fetch(nx, ny);                                 // (one step beyond the run's last: inside the window, unused)
       __builtin_amdgcn_sched_barrier(0);             // keep the reads up here (the scheduler sinks them to their use)
-      ar0 = M::mma(hr, bx[0] + by[0], ar0);
-      ai0 = M::mma(hi, bx[0] - by[0], ai0);
-      ar1 = M::mma(hr, bx[1] + by[1], ar1);
-      ai1 = M::mma(hi, bx[1] - by[1], ai1);
-      ar2 = M::mma(hr, bx[2] + by[2], ar2);
-      ai2 = M::mma(hi, bx[2] - by[2], ai2);
-      ar3 = M::mma(hr, bx[3] + by[3], ar3);
-      ai3 = M::mma(hi, bx[3] - by[3], ai3);
+      ar0 = M::mma(hr[s], bx[0] + by[0], ar0);
+      ai0 = M::mma(hi[s], bx[0] - by[0], ai0);
+      ar1 = M::mma(hr[s], bx[1] + by[1], ar1);
+      ai1 = M::mma(hi[s], bx[1] - by[1], ai1);
+      ar2 = M::mma(hr[s], bx[2] + by[2], ar2);
+      ai2 = M::mma(hi[s], bx[2] - by[2], ai2);
+      ar3 = M::mma(hr[s], bx[3] + by[3], ar3);
+      ai3 = M::mma(hi[s], bx[3] - by[3], ai3);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         bx[q] = nx[q];
         by[q] = ny[q];
       }
-    };
-    // coefficients are requested four K steps ahead of their use
-    int s = 0;
-    T nr[4], ni[4];
-    if (n >= 4) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        nr[q] = cr[64 * q];
-        ni[q] = ci[64 * q];
-      }
     }
-    for (; s + 4 <= n; s += 4) {
-      T kr[4], ki[4];
+  }
+  const Acc accr[4] = {ar0, ar1, ar2, ar3}, acci[4] = {ai0, ai1, ai2, ai3};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        kr[q] = nr[q];
-        ki[q] = ni[q];
-      }
-      if (s + 8 <= n) {
+  for (int i = 0; i < 4; ++i) {
+    const int b = kMfdBand0 + M::row(kk, i);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          nr[q] = cr[64 * (s + 4 + q)];
-          ni[q] = ci[64 * (s + 4 + q)];
+    for (int nt = 0; nt < 4; ++nt) {
+      atomicAdd(&sh.a.re[b][16 * nt + j], (double)accr[nt][i]);
+      atomicAdd(&sh.a.im[b][16 * nt + j], (double)acci[nt][i]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The block-sum form of the long filters, bands 0 .. 23 (peaq_device.h kBs*; fbearmodel.c:399-435 are the sums it
+// evaluates).  A wave takes three PAIRS of neighbouring bands and, pair by pair, all on its own (no workgroup barrier):
+//   head tile   D[16 rows][64 columns] = coef[16][32] x (32 samples x 64 window columns from bs_col_head on):
+//               per band the three exponentials' ENTER rows (re, im) and the filter's own coefficients on the
+//               block its window ENDS in, 32 matrix instructions, written to the wave's staging rows by output;
+//   tail tile   the same for MINUS the LEAVE rows and the block the window STARTS in (columns from bs_col_tail on),
+//               added on top with ds_add_f64;
+//   chain       lanes = outputs: V_i(t) = rot_i V_i(t-1) + (enter - leave)(t) as a complex prefix scan over the
+//               wave (DPP row shifts + three row carries), y(t) = V_0 + V_1 + V_2 + edges.
+// The running sums are carried from tile to tile in LDS (vst); the first tile of a launch starts them from the
+// window itself: the head tile once more on the 64 columns in front, scanned with nothing leaving, gives
+// V(-1) -- so nothing about the filters is state beyond the 1456 samples of history the direct form needs,
+// and rounding errors cannot travel further than a launch.
+// ---------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) double kdouble;   // read through the scalar cache when the address is uniform
+constexpr int kStRow = 80;                           // staging row stride in doubles (= 16 mod 32: four rows, two bank halves)
+constexpr int kStOrg = 8;                            // index of output 0 in a row (entries in front: outputs < 0 of the shifted rows)
+constexpr int kStWave = 16 * kStRow;                 // doubles per wave
+constexpr int kStRunIn = 3;                          // the run-in's tile starts 64 - 3 columns before the tile's (bs_pair)
+static_assert(4 * kStWave <= 2 * kFbBands * kACols, "the staging rows of the four waves live where A will be");
+
+__device__ __forceinline__ void bs_tile(const double* __restrict__ win, const double* __restrict__ coef, int col0, int lane,
+                                        v4d (&acc)[4]) {
+  const int j = lane & 15, kk = lane >> 4;
+  // B operand of K step ks, column tile nt: samples 4 ks + kk of the blocks col0 + 16 nt + j (rows of the window
+  // array are samples-in-block, its columns blocks: consecutive lanes read consecutive doubles)
+  const double* p = win + kk * kWinRow + col0 + j;
+  double a[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) a[ks] = coef[ks * 64 + lane];
+  const v4d zero = {0, 0, 0, 0};
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = zero;
+  double b[4], nb[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) b[nt] = lds_rd(p + 16 * nt);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    if (ks < 7) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) nb[nt] = lds_rd(p + 4 * (ks + 1) * kWinRow + 16 * nt);
+    }
+    __builtin_amdgcn_sched_barrier(0);               // the next step's reads stay ahead of this step's matrix instructions
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) b[nt] = nb[nt];
+  }
+}
+
+// inclusive complex prefix scan over the lanes with ratio r: lane t gets sum_{s <= t} r^(t - s) u_s.
+// rot[k] = r^(2^k), k = 0..4; (pw_re, pw_im) = r^((lane & 15) + 1).
+__device__ __forceinline__ void bs_scan(double& re, double& im, const double (&rot)[5][2], double pw_re, double pw_im,
+                                        int lane) {
+#define PEAQ_BS_LEVEL(SH, K)                                                        \
+  {                                                                                 \
+    const double sr = dpp_d0<kDppRowShr + SH>(re), si = dpp_d0<kDppRowShr + SH>(im); \
+    re = fma(rot[K][0], sr, fma(-rot[K][1], si, re));                               \
+    im = fma(rot[K][0], si, fma(rot[K][1], sr, im));                                \
+  }
+  PEAQ_BS_LEVEL(1, 0)
+  PEAQ_BS_LEVEL(2, 1)
+  PEAQ_BS_LEVEL(4, 2)
+  PEAQ_BS_LEVEL(8, 3)
+#undef PEAQ_BS_LEVEL
+  // prefix totals at the last lane of rows 0, 1, 2 carried into the rows behind them
+  const double t0r = read_lane<15>(re), t0i = read_lane<15>(im);
+  const double t1r = fma(rot[4][0], t0r, fma(-rot[4][1], t0i, read_lane<31>(re)));
+  const double t1i = fma(rot[4][0], t0i, fma(rot[4][1], t0r, read_lane<31>(im)));
+  const double t2r = fma(rot[4][0], t1r, fma(-rot[4][1], t1i, read_lane<47>(re)));
+  const double t2i = fma(rot[4][0], t1i, fma(rot[4][1], t1r, read_lane<47>(im)));
+  const int row = lane >> 4;
+  const double cr = row == 0 ? 0. : row == 1 ? t0r : row == 2 ? t1r : t2r;
+  const double ci = row == 0 ? 0. : row == 1 ? t0i : row == 2 ? t1i : t2i;
+  re = fma(pw_re, cr, fma(-pw_im, ci, re));
+  im = fma(pw_re, ci, fma(pw_im, cr, im));
+}
+
+// one pair of bands (2 p, 2 p + 1): their filter outputs at the tile's outputs lane = 0 .. 59 -> (yr, yi)[band in pair].
+// The first tile of a launch walks the code twice: pass 0 is the run-in (the outputs BEFORE the tile, lane l <->
+// output l - 64: enter rows only, nothing leaves; band b's sums hold its bs_whole[b] <= 44 newest whole columns,
+// older outputs do not count; result: V(-1)), pass 1 the tile itself.  One body for both keeps the kernel's code
+// inside the instruction cache -- unrolled, this phase alone was as long as the rest of the kernel and every
+// phase ran a fifth slower.
+__device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* __restrict__ stg, double (*vst)[2],
+                                        const FbTables* __restrict__ fb, int p, bool first_tile, int nvs, int lane,
+                                        double (&yr)[2], double (&yi)[2]) {
+  const int j = lane & 15, kk = lane >> 4;
+  const int col_head = fb->bs_col_head[p], col_tail = fb->bs_col_tail[p];
+  // staging index of accumulator element i (row kk + 4 i: band i >> 1 of the pair, type kk + 4 (i & 1)) of column tile 0
+  int ih[4], it[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = 2 * p + (i >> 1), ty = kk + 4 * (i & 1);
+    const int at = (kk + 4 * i) * kStRow + kStOrg + j;
+    ih[i] = at - fb->bs_off_enter[b] - (ty >= 6 ? 1 : 0);
+    it[i] = at - fb->bs_off_leave[b];
+  }
+#pragma unroll 1
+  for (int pass = first_tile ? 0 : 1; pass < 2; ++pass) {
+    const bool run_in = pass == 0;
+    v4d acc[4];
+    // (run-in: output -1 of a band whose rows sit bs_off_enter <= 2 columns into the tile reads column
+    // col_head + 1 -- the run-in's 64 columns end at col_head + kStRunIn - 1)
+    const int shift = run_in ? kStRunIn : 0;
+    bs_tile(win, fb->bs_coef[p][0][0], run_in ? col_head - 64 + kStRunIn : col_head, lane, acc);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) stg[ih[i] + shift + 16 * nt] = acc[nt][i];
+    if (!run_in) {
+      bs_tile(win, fb->bs_coef[p][1][0], col_tail, lane, acc);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&stg[it[i] + 16 * nt], acc[nt][i]);
+    }
+    wave_lds_fence();
+    const int last = run_in ? 63 : nvs - 1;            // the lane whose sums go on (to the tile / to the next tile)
+#pragma unroll 1
+    for (int sub = 0; sub < 2; ++sub) {
+      const bool live = !run_in || lane >= 64 - fb->bs_whole[2 * p + sub];
+      const double* urow = stg + 8 * sub * kStRow + kStOrg + lane;
+      double sr = urow[6 * kStRow], si = urow[7 * kStRow];   // the two edge blocks
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int c = 6 * p + 3 * sub + e;
+        double re = live ? urow[2 * e * kStRow] : 0., im = live ? urow[(2 * e + 1) * kStRow] : 0.;
+        // the chain's constants: r^(1, 2, 4, 8, 16) through the scalar cache (the table is read as constant
+        // memory: as ordinary global loads the six chains' constants sat in 120 vector registers and pushed
+        // the kernel's other state into scratch), r^((lane & 15) + 1) per lane
+        const kdouble* rk = (const kdouble*)(const void*)&fb->bs_rot[c][0][0];
+        const double rot[5][2] = {{rk[0], rk[1]}, {rk[2], rk[3]}, {rk[4], rk[5]}, {rk[6], rk[7]}, {rk[8], rk[9]}};
+        const double2 pw = *reinterpret_cast<const double2*>(fb->bs_pow[c][j]);
+        if (lane == 0 && !run_in) {                    // rot V(-1) joins the first output
+          const double vr = vst[c][0], vi = vst[c][1];
+          re = fma(rot[0][0], vr, fma(-rot[0][1], vi, re));
+          im = fma(rot[0][0], vi, fma(rot[0][1], vr, im));
         }
+        bs_scan(re, im, rot, pw.x, pw.y, lane);
+        const double vr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(re), last),
+                                           __builtin_amdgcn_readlane(__double2loint(re), last));
+        const double vi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(im), last),
+                                           __builtin_amdgcn_readlane(__double2loint(im), last));
+        if (lane == 0) {
+          vst[c][0] = vr;
+          vst[c][1] = vi;
+        }
+        sr += re;
+        si += im;
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) step(kr[q], ki[q]);
+      yr[0] = sub == 0 ? sr : yr[0];
+      yi[0] = sub == 0 ? si : yi[0];
+      yr[1] = sr;                                      // (the second band's pass leaves its own here)
+      yi[1] = si;
     }
-    for (; s < n; ++s) step(cr[64 * s], ci[64 * s]);
-    const Acc accr[4] = {ar0, ar1, ar2, ar3}, acci[4] = {ai0, ai1, ai2, ai3};
-    fir_store<M>(sh, sg.r, j, kk, accr, acci);
-    g += n;
+    wave_lds_fence();                                  // the next tiles overwrite the staging rows
   }
 }
 
@@ -780,7 +935,14 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
 #ifdef PEAQ_FB_PROFILE
   unsigned long long prof_t_ = __builtin_readcyclecounter();
 #endif
+  const int tid_k = tid, lane_k = lane, wv_k = wv;
   for (unsigned b0 = 0; b0 < nb_mine; b0 += kTileBlocks) {
+    // The thread's indices are re-derived (as far as the compiler can tell) in every tile: otherwise it computes the
+    // LDS addresses of ALL phases once in front of the loop -- some two hundred registers, most of which the FP64
+    // engine's phases then push into scratch memory, whose reloads cost every phase a multiple of its time.
+    int tid_v = tid_k, lane_v = lane_k, wv_s = wv_k;
+    asm volatile("" : "+v"(tid_v), "+v"(lane_v), "+s"(wv_s));
+    const int tid = tid_v, lane = lane_v, wv = wv_s;
     const unsigned nvb = min((unsigned)kTileBlocks, nb_mine - b0);   // valid blocks in this tile
 #ifdef PEAQ_FB_PROFILE
     if (lane == 0 && (blockIdx.x & 15) == 5) atomicAdd(&g_fb_prof[64 + wv], 1ull);
@@ -795,6 +957,11 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     if (b0 == 0) {
       if constexpr (sizeof(WT) == 2)                 // beyond the window proper: read by the unused time points 60..63 only
         for (int wdx = kWin + tid; wdx < 32 * kWinHBlocks; wdx += 256) sh.win.put(wdx, 0., 0.);
+      if constexpr (sizeof(WT) == 8)                 // block-sum form: its tiles span 64 columns (outputs 60..63 are never
+        for (int e = tid; e < 32 * 8; e += 256) {    // used) and whole blocks (the coefficients beyond a window's end are 0)
+          const int r = e >> 3, c = kWinRow - 8 + (e & 7);
+          if (32 * c + r >= kWin) sh.win.v[r * kWinRow + c] = 0.;
+        }
       const int avail = (int)min((size_t)kWin, row_valid);
       for (int wdx = tid; wdx < kWin; wdx += 256) sh.win.put(wdx, wdx < avail ? row[wdx] : 0., xs);
     } else {
@@ -804,22 +971,57 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         if (wdx < kWin) sh.win.put(wdx, pre[q], xs);
       }
     }
-    {
+    if constexpr (sizeof(WT) != 8) {
       double2* az = reinterpret_cast<double2*>(&sh.a.re[0][0]);
       for (int i = tid; i < kFbBands * kACols; i += 256) az[i] = make_double2(0., 0.);
     }
     __syncthreads();
     FB_MARK(0);
     // ---- phase 1: the complex FIR filters (fbearmodel.c:399-435) as a GEMM on the matrix cores ---
-    if constexpr (sizeof(WT) == 8)
-      fir_mfma<M>(sh, reinterpret_cast<const WT*>(fb->mf_re), reinterpret_cast<const WT*>(fb->mf_im), wv, lane);
-    else if constexpr (sizeof(WT) == 4)
+    if constexpr (sizeof(WT) == 8) {
+      // FP64 engine: bands 0 .. 23 in the block-sum form (three pairs per wave; the staging rows occupy what will
+      // be A, the results wait in registers), then bands 24 .. 39 as one direct tile
+      double* stg = &sh.a.re[0][0] + wv * kStWave;
+      double yr[3][2], yi[3][2];
+#pragma unroll 1
+      for (int q = 0; q < 3; ++q) {
+        double pr[2], pi[2];
+        bs_pair(reinterpret_cast<const double*>(sh.win.v), stg, sh.vst, fb, wv + 4 * q, b0 == 0, nvs, lane, pr, pi);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)                    // (uniform selects: the loop is not unrolled, y stays in registers)
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+            yr[k][sub] = q == k ? pr[sub] : yr[k][sub];
+            yi[k][sub] = q == k ? pi[sub] : yi[k][sub];
+          }
+      }
+      FB_MARK(13);
+      __syncthreads();                                               // every wave is done with its staging rows
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          // (outputs 60..63 do not exist: what the scan left there is whatever the staging rows held)
+          sh.a.re[2 * (wv + 4 * q) + sub][lane] = lane < kTileSub ? yr[q][sub] : 0.;
+          sh.a.im[2 * (wv + 4 * q) + sub][lane] = lane < kTileSub ? yi[q][sub] : 0.;
+        }
+      for (int i = tid; i < (kFbBands - kMfdBand0) * kACols; i += 256) {
+        (&sh.a.re[kMfdBand0][0])[i] = 0.;
+        (&sh.a.im[kMfdBand0][0])[i] = 0.;
+      }
+      __syncthreads();
+      FB_MARK(14);
+      fir_mfma_tail<M>(sh, reinterpret_cast<const WT*>(fb->mfd_re), reinterpret_cast<const WT*>(fb->mfd_im), wv, lane);
+    } else if constexpr (sizeof(WT) == 4)
       fir_mfma_f32(sh, fb->mf_re_f, fb->mf_im_f, wv, lane);
     else
       fir_mfma_h3(sh, fb, xus, wv, lane);
     FB_MARK(1);
     __syncthreads();                                                 // A is complete
     FB_MARK(2);
+#ifdef PEAQ_DEV_DUMP_FIR                             // development (dev_probes.inc): the raw filter outputs instead of the patterns
+    PEAQ_DEV_DUMP_FIR_SAVE
+#endif
     // ---- phase 2a: every wave picks up its ten bands at its time point ---------------------------
     double re[10], im[10];
 #pragma unroll
@@ -979,6 +1181,9 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
       rec[(sig ? kFbRecUnsmTest : kFbRecUnsmRef) + b] = sh.e1[b][bl];
       rec[(sig ? kFbRecExcTest : kFbRecExcRef) + b] = sh.ex[b][bl];
     }
+#ifdef PEAQ_DEV_DUMP_FIR
+    PEAQ_DEV_DUMP_FIR_WRITE
+#endif
     FB_MARK(12);
   }
   __syncthreads();

@@ -12,6 +12,7 @@
 //   EHS window             movs.c:1360-1368
 #include "peaq_tables.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -257,6 +258,88 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
       }
     }
   }
+  // The FP64 engine's tables (peaq_device.h kBs*, kMfd*).  Direct tile first: bands 24 .. 39, as above.
+  if (fb.delay[kMfdBand0] + 1 != kMfdD0 || (kFbCentre - kMfdD0) / 4 + 1 != kMfdSteps) std::abort();
+  for (int s = 0; s < kMfdSteps; ++s)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int b = kMfdBand0 + (lane & 15), d = kMfdD0 + 4 * s + (lane >> 4);
+      const int half = kLen[b] / 2, n = d - fb.delay[b];
+      double vr = 0., vi = 0.;
+      if (n >= 1 && n <= half) {
+        vr = fb.h_re[fb.coef_off[b] + n] * (n == half ? 0.5 : 1.);
+        vi = n == half ? 0. : fb.h_im[fb.coef_off[b] + n];
+      }
+      fb.mfd_re[(size_t)s * 64 + lane] = vr;
+      fb.mfd_im[(size_t)s * 64 + lane] = vi;
+    }
+  // Block-sum form of bands 0 .. 23.  In window coordinates (sample u of the kernel's window; output t has its
+  // filters' centre tap on u = 727 + 32 t, i.e. delay 729) tap m = u - 727 - 32 t of band b carries
+  //   h(m) = 4/N cos^2(pi m / N) W e^(-j w m),  |m| < N/2      (fbearmodel.c:214-220 with n = N/2 - m)
+  //        = sum_i g_i e^(-j w_i m),  (g_i, w_i) = (2W/N, w), (W/N, w + 2 pi/N), (W/N, w - 2 pi/N).
+  {
+    const long double pi = 3.14159265358979323846264338327950288L;
+    int cL[kBsBands], cR[kBsBands];
+    for (int b = 0; b < kBsBands; ++b) {
+      const int half = kLen[b] / 2;
+      cL[b] = (728 - half) >> 5;
+      cR[b] = (726 + half) >> 5;
+      fb.bs_whole[b] = cR[b] - 1 - cL[b];
+      if (fb.bs_whole[b] < 1 || fb.bs_whole[b] > 44) std::abort();
+    }
+    for (int p = 0; p < kBsPairs; ++p) {
+      const int b0 = 2 * p, b1 = 2 * p + 1;
+      fb.bs_col_head[p] = std::min(cR[b0], cR[b1]) - 1;
+      fb.bs_col_tail[p] = std::min(cL[b0], cL[b1]);
+      for (int b = b0; b <= b1; ++b) {
+        fb.bs_off_enter[b] = cR[b] - 1 - fb.bs_col_head[p];
+        fb.bs_off_leave[b] = cL[b] - fb.bs_col_tail[p];
+        // the kernel's tiles span 64 columns for 60 outputs, an edge row sits one column beyond its enter rows
+        if (fb.bs_off_enter[b] < 0 || fb.bs_off_enter[b] > 2 || fb.bs_off_leave[b] < 0 || fb.bs_off_leave[b] > 3)
+          std::abort();
+      }
+    }
+    for (int b = 0; b < kBsBands; ++b) {
+      const int n_taps = kLen[b], half = n_taps / 2, p = b / 2, sub = b & 1;
+      const long double w0 = 2 * pi * (long double)fc[b] / 48000.0L, dw = 2 * pi / n_taps;
+      const long double wi[3] = {w0, w0 + dw, w0 - dw};
+      const long double wt = ear_weight_db_to_lin(fc[b]);
+      const long double gi[3] = {2 * wt / n_taps, wt / n_taps, wt / n_taps};
+      // the filter's own coefficient at window offset m (re, im), from the table the direct form uses
+      auto own = [&](int m, double& vr, double& vi) {
+        const int n = half - std::abs(m);
+        vr = vi = 0.;
+        if (n < 1) return;                               // beyond the window (h(N/2 - 0) = h(0) = 0 as well)
+        vr = fb.h_re[fb.coef_off[b] + n];
+        vi = m == 0 ? 0. : (m > 0 ? fb.h_im[fb.coef_off[b] + n] : -fb.h_im[fb.coef_off[b] + n]);
+      };
+      for (int which = 0; which < 2; ++which)            // 0 = head tile (enter, right edge), 1 = tail tile (leave, left edge)
+        for (int q = 0; q < 32; ++q) {
+          const int c_sum = which == 0 ? cR[b] - 1 : cL[b];      // column (relative to t) of the three-exponential rows
+          const int c_own = which == 0 ? cR[b] : cL[b];          // ... of the edge row
+          double row[8];
+          for (int i = 0; i < 3; ++i) {
+            const long double ph = wi[i] * (long double)(32 * c_sum + q - 727);
+            const long double sgn = which == 0 ? 1.0L : -1.0L;   // the leaving block is subtracted
+            row[2 * i] = (double)(sgn * gi[i] * std::cos(ph));
+            row[2 * i + 1] = (double)(-sgn * gi[i] * std::sin(ph));
+          }
+          own(32 * c_own + q - 727, row[6], row[7]);
+          for (int ty = 0; ty < 8; ++ty) fb.bs_coef[p][which][q / 4][(8 * sub + ty) + 16 * (q & 3)] = row[ty];
+        }
+      for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k < 5; ++k) {
+          const long double ph = 32.0L * wi[i] * (long double)(1 << k);
+          fb.bs_rot[3 * b + i][k][0] = (double)std::cos(ph);
+          fb.bs_rot[3 * b + i][k][1] = (double)std::sin(ph);
+        }
+        for (int l = 0; l < 16; ++l) {
+          const long double ph = 32.0L * wi[i] * (long double)(l + 1);
+          fb.bs_pow[3 * b + i][l][0] = (double)std::cos(ph);
+          fb.bs_pow[3 * b + i][l][1] = (double)std::sin(ph);
+        }
+      }
+    }
+  }
   for (int k = 0; k < 6; ++k) {
     const double c = std::cos(kPi * (k - 5.0) / 12.0);
     fb.back_mask[k] = c * c * 0.9761 / 6.0;
@@ -316,6 +399,89 @@ void build_common_tables(CommonTables& c) {
     c.log_tab[i][1] = (double)(i < kLogTabFold ? std::log(c_eff) : std::log(c_eff) - ln2);
   }
   c.log_tab[128][1] = 0.;                             // ln 2 - ln 2 (the long-double difference is 0 anyway)
+}
+
+// Self-check of the FP64 engine's filter-bank tables on the host (no device involved; tests/test_capi_host.py):
+// the block-sum form of bands 0 .. 23 and the direct tile of bands 24 .. 39, evaluated from FbTables on a window of
+// pseudo-random samples, against the plain sums of fbearmodel.c:399-435 over the same coefficients
+// (FbTables::h_re / h_im).  Returns the largest deviation relative to the largest output of its band.
+double fb_tables_selfcheck() {
+  std::vector<BandTables> bt(1);
+  std::vector<FbTables> fbv(1);
+  build_fb_band_tables(bt[0], fbv[0]);
+  const FbTables& fb = fbv[0];
+  constexpr int kOut = 60, kCols = 112;
+  std::vector<double> x(32 * kCols, 0.);                   // window sample u = 32 column + row
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  for (int u = 0; u < kFbRing + 32 * kOut; ++u) {
+    st = st * 6364136223846793005ull + 1442695040888963407ull;
+    x[u] = (double)(int64_t)(st >> 11) / 4503599627370496.0 - 1.0 + 0.5 * std::sin(0.013 * u);
+  }
+  double worst = 0.;
+  for (int b = 0; b < kFbBands; ++b) {
+    const int half = fb.flen[b] / 2, off = fb.coef_off[b];
+    // the reference's sum: taps n = 1 .. N - 1 at delays D + n, i.e. window samples 727 + N/2 - n + 32 t
+    std::vector<double> dr(kOut), di(kOut);
+    double peak = 0.;
+    for (int t = 0; t < kOut; ++t) {
+      long double re = 0, im = 0;
+      for (int n = 1; n < fb.flen[b]; ++n) {
+        const int k = n <= half ? n : fb.flen[b] - n;
+        const double hr = fb.h_re[off + k], hi = n <= half ? fb.h_im[off + k] : -fb.h_im[off + k];
+        const double v = x[727 + half - n + 32 * t];
+        re += (long double)hr * v;
+        im += (long double)(n == half ? 0. : hi) * v;
+      }
+      dr[t] = (double)re;
+      di[t] = (double)im;
+      peak = std::max(peak, std::hypot(dr[t], di[t]));
+    }
+    std::vector<double> yr(kOut, 0.), yi(kOut, 0.);
+    if (b < kBsBands) {
+      const int p = b / 2, sub = b & 1;
+      auto row_dot = [&](int which, int ty, int col) {     // one row of the pair's head / tail tile on window column col
+        double acc = 0.;
+        for (int q = 0; q < 32; ++q)
+          acc += fb.bs_coef[p][which][q / 4][(8 * sub + ty) + 16 * (q & 3)] * (col >= 0 ? x[32 * col + q] : 0.);
+        return acc;
+      };
+      for (int i = 0; i < 3; ++i) {
+        const double rr = fb.bs_rot[3 * b + i][0][0], ri = fb.bs_rot[3 * b + i][0][1];
+        double vr = 0., vi = 0.;
+        for (int t = -fb.bs_whole[b]; t < kOut; ++t) {     // run-in with nothing leaving, then the tile
+          const int ch = fb.bs_col_head[p] + t + fb.bs_off_enter[b], ct = fb.bs_col_tail[p] + t + fb.bs_off_leave[b];
+          double ur = row_dot(0, 2 * i, ch), ui = row_dot(0, 2 * i + 1, ch);
+          if (t >= 0) {
+            ur += row_dot(1, 2 * i, ct);
+            ui += row_dot(1, 2 * i + 1, ct);
+          }
+          const double nr = rr * vr - ri * vi + ur, ni = rr * vi + ri * vr + ui;
+          vr = nr;
+          vi = ni;
+          if (t >= 0) {
+            yr[t] += vr;
+            yi[t] += vi;
+          }
+        }
+      }
+      for (int t = 0; t < kOut; ++t) {
+        const int ch = fb.bs_col_head[p] + t + fb.bs_off_enter[b] + 1, ct = fb.bs_col_tail[p] + t + fb.bs_off_leave[b];
+        yr[t] += row_dot(0, 6, ch) + row_dot(1, 6, ct);
+        yi[t] += row_dot(0, 7, ch) + row_dot(1, 7, ct);
+      }
+    } else {
+      for (int t = 0; t < kOut; ++t)
+        for (int s = 0; s < kMfdSteps; ++s)
+          for (int kk = 0; kk < 4; ++kk) {
+            const int d = kMfdD0 + 4 * s + kk, lane = (b - kMfdBand0) + 16 * kk;
+            const double x1 = x[kFbRing - d + 32 * t], x2 = x[d - 2 + 32 * t];
+            yr[t] += fb.mfd_re[(size_t)s * 64 + lane] * (x1 + x2);
+            yi[t] += fb.mfd_im[(size_t)s * 64 + lane] * (x1 - x2);
+          }
+    }
+    for (int t = 0; t < kOut; ++t) worst = std::max(worst, std::hypot(yr[t] - dr[t], yi[t] - di[t]) / peak);
+  }
+  return worst;
 }
 
 double fft_level_factor(double level_db) {

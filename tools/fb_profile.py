@@ -16,9 +16,13 @@ import gstpeaq_amd  # noqa: E402
 PHASES = ["0 window + zero A + barrier", "1 FIR (own run of K steps)", "2 barrier after the FIR", "3 pick up bands + barrier",
           "4 shift window, request next", "5 log/exp/slope scan (10 bands)", "6 upward spreading", "7 barrier",
           "8 downward spreading + barrier", "9 backward masking + barrier", "10 history + barrier",
-          "11 forward masking + barrier", "12 records"]
+          "11 forward masking + barrier", "12 records",
+          "13 FP64 engine: block-sum form of bands 0..23 (inside 1)", "14 FP64 engine: barrier, results -> A, barrier (inside 1)"]
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+MODE = sys.argv[2] if len(sys.argv) > 2 else None      # "f64": the FP64 engine
 ctx = gstpeaq_amd.Context(0)
+if MODE == "f64":
+    ctx.set_fir_fp64(True)
 ref, test = gstpeaq_amd.synth_fill(ctx, 1, pairs, 2, 480000)
 buf = (C.c_ulonglong * 68)()
 ctx.L.peaq_debug_fb_profile.argtypes = [C.POINTER(C.c_ulonglong)]
