@@ -47,14 +47,18 @@ enum { HF_RE_HI_1, HF_RE_LO_1, HF_IM_HI_1, HF_IM_LO_1, HF_RE_HI_2, HF_RE_LO_2, H
 // windows, 4/N cos^2(pi m/N) e^(-j w m) = sum_i g_i e^(-j w_i m) with w_i = w, w + 2 pi/N, w - 2 pi/N, so the
 // part of a filter's window that consists of WHOLE 32-sample blocks of the signal is, per exponential, a
 // running sum along the outputs (one every 32 samples): V(t) = e^(j 32 w_i) V(t-1) + enter(t) - leave(t), where
-// enter / leave are dot products of ONE block with a fixed row of 32 coefficients.  Only the two blocks the
-// window's ends fall into need the filter's own coefficients.  Per band and output that is 16 rows of 32
-// multiply-adds (6 enter, 6 leave, 2 + 2 edge) whatever the filter's length, against N for the direct form:
-// the bands 0 .. kBsBands-1 (N >= 262) run this way, two bands per 16-row tile of the matrix instruction,
-// the rest as one direct (folded) GEMM tile like before.
+// enter is the dot product of the block that became whole with a fixed row of 32 coefficients and leave that of
+// the block that stopped being whole -- the same block's enter value of J outputs ago (J = the window's whole
+// blocks) times the constant e^(j 32 w_i J), so it is taken from a history of the last J enter values
+// (FbSignalState::bs_hist) instead of being computed again.  Only the two blocks the window's ends fall into
+// need the filter's own coefficients.  Per band and output that is 8 rows of 32 multiply-adds on the matrix
+// cores (6 enter, 2 for the block the window ends in) and one row on the vector ALU (the block it starts in),
+// whatever the filter's length, against N for the direct form: the bands 0 .. kBsBands-1 (N >= 262) run this
+// way, two bands per 16-row tile of the matrix instruction, the rest as one direct (folded) GEMM tile.
 constexpr int kBsBands  = 24;
 constexpr int kBsPairs  = kBsBands / 2;
 constexpr int kBsChains = kBsBands * 3;
+constexpr int kBsHist   = 44;     // the longest filter's whole blocks
 // the direct tile: bands 24 .. 39, delays kMfdD0 .. 729 in kMfdSteps K steps of four
 constexpr int kMfdBand0 = 24;
 constexpr int kMfdD0    = 611;
@@ -140,16 +144,20 @@ struct FbTables {               // fbearmodel.c:57-61,182-225
   // ---- block-sum form (kBs* above).  Window columns are blocks of 32 samples (column c = samples 32 c .. 32 c + 31
   // of the kernel's window, whose sample 727 + 32 t is the centre of every filter at output t).  Band b's window at
   // t = 0 is [728 - N/2, 726 + N/2]: cL = first column it touches, cR = last; columns cL+1 .. cR-1 are whole.
-  int    bs_col_head[kBsPairs];         // first column of the pair's head tile at t = 0: min(cR) - 1
-  int    bs_col_tail[kBsPairs];         // ... of its tail tile: min(cL)
+  int    bs_col_head[kBsPairs];         // first column of the pair's tile at t = 0: min(cR) - 1
   int    bs_off_enter[kBsBands];        // column of band b's enter rows at output t: bs_col_head + t + this (edge rows: + 1)
-  int    bs_off_leave[kBsBands];        // column of its leave and left-edge rows:     bs_col_tail + t + this
+  int    bs_col_left[kBsBands];         // cL: column (at t = 0) of the block the window starts in
+  int    bs_left_q0[kBsBands];          // first sample of that block inside the window
   int    bs_whole[kBsBands];            // J = cR - 1 - cL whole columns
-  // A operands: [pair][head, tail][K step][lane = row + 16 (k mod 4)], row = 8 (band in pair) + type,
-  // type 0..5 = re, im of the three exponentials (head: enter, tail: MINUS leave), 6, 7 = re, im of the edge block
-  double bs_coef[kBsPairs][2][8][64];
-  double bs_rot[kBsChains][5][2];       // chain = 3 band + i: e^(j 32 w_i k), k = 1, 2, 4, 8, 16 (re, im)
-  double bs_pow[kBsChains][16][2];      // e^(j 32 w_i (l + 1)), l = 0..15
+  // A operands: [pair][K step][lane = row + 16 (k mod 4)], row = 8 (band in pair) + type,
+  // type 0..5 = re, im of the three exponentials' enter rows, 6, 7 = re, im of the block the window ends in
+  double bs_coef[kBsPairs][8][64];
+  // the filter's own coefficients on the block the window starts in: entry e = 2 q + (0 re, 1 im) of sample q
+  // at [e & 15][e >> 4] -- lane l keeps the four entries l & 15, 16 + (l & 15), ... as one 32-byte read, and a tap's
+  // coefficient reaches all lanes as a DPP row broadcast
+  double bs_left[kBsBands][16][4];
+  double bs_rot[kBsChains][2][2];       // chain = 3 band + i: rot = e^(j 32 w_i) and rot^J (re, im)
+  double bs_pow[kBsChains][64][2];      // rot^(l + 1), l = 0..63
   double mfd_re[kMfdSteps * 64];        // the direct tile's A operands, lane = band - 24 + 16 (d - kMfdD0 - 4 s)
   double mfd_im[kMfdSteps * 64];
 };
@@ -270,6 +278,9 @@ struct FbSignalState {
   // i + 1 runs beside the bank kernel of launch i -- and peak_last what the next walk will call "previous".
   double peak_slot[3][2];
   double peak_last;
+  // FP64 engine, block-sum form of the long filters (kBs*): per band and exponential the last J = bs_whole[band]
+  // enter values (re, im), oldest first -- what the direct form's delay line is to the samples
+  double bs_hist[kBsBands][6][kBsHist];
 };
 
 }  // namespace peaq

@@ -261,8 +261,8 @@ struct Window<_Float16> {
 
 template <typename WT>
 struct BankLds {
-  // (the window is not the first member: the run-in of the block-sum form, bs_pair below, reads up to 39 columns
-  // in front of it -- values it then discards -- and those addresses must stay inside the allocation)
+  // (the window is not the first member: bs_pair below reads up to 44 entries in front of a staging row -- values it
+  // then discards -- and those addresses must stay inside the allocation whichever wave's rows they are)
   double hist[kFbBands][10];       // the 10 newest E0 values of the previous tile, oldest first
   double cu[kFbBands];
   double c0[kFbBands];             // ln DIST (24 + 230 / fc): constant of the slope exponent, per band
@@ -441,34 +441,39 @@ __device__ __forceinline__ void fir_mfma_tail(BankLds<typename M::T>& sh, const 
 // ---------------------------------------------------------------------------
 // The block-sum form of the long filters, bands 0 .. 23 (peaq_device.h kBs*; fbearmodel.c:399-435 are the sums it
 // evaluates).  A wave takes three PAIRS of neighbouring bands and, pair by pair, all on its own (no workgroup barrier):
-//   head tile   D[16 rows][64 columns] = coef[16][32] x (32 samples x 64 window columns from bs_col_head on):
-//               per band the three exponentials' ENTER rows (re, im) and the filter's own coefficients on the
-//               block its window ENDS in, 32 matrix instructions, written to the wave's staging rows by output;
-//   tail tile   the same for MINUS the LEAVE rows and the block the window STARTS in (columns from bs_col_tail on),
-//               added on top with ds_add_f64;
-//   chain       lanes = outputs: V_i(t) = rot_i V_i(t-1) + (enter - leave)(t) as a complex prefix scan over the
-//               wave (DPP row shifts + three row carries), y(t) = V_0 + V_1 + V_2 + edges.
-// The running sums are carried from tile to tile in LDS (vst); the first tile of a launch starts them from the
-// window itself: the head tile once more on the 64 columns in front, scanned with nothing leaving, gives
-// V(-1) -- so nothing about the filters is state beyond the 1456 samples of history the direct form needs,
-// and rounding errors cannot travel further than a launch.
+//   tile     D[16 rows][64 columns] = coef[16][32] x (32 samples x 64 window columns from bs_col_head on): per band
+//            the three exponentials' ENTER rows (re, im) and the filter's own coefficients on the block its window
+//            ENDS in -- 32 matrix instructions, written to the wave's staging rows by output;
+//   left     the filter's own coefficients on the block the window STARTS in: at most 32 taps on the vector ALU,
+//            lanes = outputs (two rows of sixteen would fill a matrix tile to a quarter);
+//   chain    lanes = outputs: V_i(t) = rot_i V_i(t-1) + enter(t) - rot_i^J enter(t - J) as a complex prefix scan
+//            over the wave (DPP row shifts + three row carries), y(t) = V_0 + V_1 + V_2 + the two edge blocks.
+//            enter(t - J) is read from the staging rows, or for the tile's first J outputs from the history
+//            (FbSignalState::bs_hist: the last J enter values per exponential, re-written after every tile).
+// The running sums V are carried from tile to tile in LDS (vst); the first tile of a launch computes them from the
+// history (V(-1) = sum_s rot^s enter(-1 - s): one more scan) -- so the only state is the history, which is exact:
+// rounding errors of the sums cannot travel further than a launch, and nothing is left of a sample 1456 samples
+// after it, as in the reference's delay line.
 // ---------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) double kdouble;   // read through the scalar cache when the address is uniform
+typedef const __attribute__((address_space(4))) int kint;
 constexpr int kStRow = 80;                           // staging row stride in doubles (= 16 mod 32: four rows, two bank halves)
 constexpr int kStOrg = 8;                            // index of output 0 in a row (entries in front: outputs < 0 of the shifted rows)
 constexpr int kStWave = 16 * kStRow;                 // doubles per wave
-constexpr int kStRunIn = 3;                          // the run-in's tile starts 64 - 3 columns before the tile's (bs_pair)
 static_assert(4 * kStWave <= 2 * kFbBands * kACols, "the staging rows of the four waves live where A will be");
 
-__device__ __forceinline__ void bs_tile(const double* __restrict__ win, const double* __restrict__ coef, int col0, int lane,
-                                        v4d (&acc)[4]) {
+// the A operands of a pair's tile (eight K steps): requested a pair ahead of their use
+__device__ __forceinline__ void bs_coef_load(const FbTables* __restrict__ fb, int p, int lane, double (&a)[8]) {
+  const double* coef = fb->bs_coef[p < kBsPairs ? p : kBsPairs - 1][0] + lane;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) a[ks] = coef[ks * 64];
+}
+
+__device__ __forceinline__ void bs_tile(const double* __restrict__ win, const double (&a)[8], int col0, int lane, v4d (&acc)[4]) {
   const int j = lane & 15, kk = lane >> 4;
   // B operand of K step ks, column tile nt: samples 4 ks + kk of the blocks col0 + 16 nt + j (rows of the window
   // array are samples-in-block, its columns blocks: consecutive lanes read consecutive doubles)
   const double* p = win + kk * kWinRow + col0 + j;
-  double a[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) a[ks] = coef[ks * 64 + lane];
   const v4d zero = {0, 0, 0, 0};
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) acc[nt] = zero;
@@ -489,114 +494,174 @@ __device__ __forceinline__ void bs_tile(const double* __restrict__ win, const do
   }
 }
 
-// inclusive complex prefix scan over the lanes with ratio r: lane t gets sum_{s <= t} r^(t - s) u_s.
-// rot[k] = r^(2^k), k = 0..4; (pw_re, pw_im) = r^((lane & 15) + 1).
-__device__ __forceinline__ void bs_scan(double& re, double& im, const double (&rot)[5][2], double pw_re, double pw_im,
-                                        int lane) {
-#define PEAQ_BS_LEVEL(SH, K)                                                        \
-  {                                                                                 \
-    const double sr = dpp_d0<kDppRowShr + SH>(re), si = dpp_d0<kDppRowShr + SH>(im); \
-    re = fma(rot[K][0], sr, fma(-rot[K][1], si, re));                               \
-    im = fma(rot[K][0], si, fma(rot[K][1], sr, im));                                \
-  }
-  PEAQ_BS_LEVEL(1, 0)
-  PEAQ_BS_LEVEL(2, 1)
-  PEAQ_BS_LEVEL(4, 2)
-  PEAQ_BS_LEVEL(8, 3)
+// The running sums of one exponential over the wave's outputs: lane t gets r^(t+1) v + sum_{s <= t} r^(t - s) u_s
+// from (pr, pi) = r^(lane + 1) alone: every input is turned back into the frame of output -1 (times conj r^(s+1)),
+// the frame's plain prefix sum is taken (DPP row shifts, three row totals through the scalar registers) and
+// turned forward again.  |r| = 1: the turns cost no accuracy.
+__device__ __forceinline__ void bs_chain(double& re, double& im, double vr, double vi, double pr, double pi, int lane) {
+  double ar = fma(pr, re, pi * im), ai = fma(pr, im, -pi * re);       // conj(p) u
+#define PEAQ_BS_LEVEL(SH)                    \
+  ar += dpp_d0<kDppRowShr + SH>(ar);         \
+  ai += dpp_d0<kDppRowShr + SH>(ai);
+  PEAQ_BS_LEVEL(1)
+  PEAQ_BS_LEVEL(2)
+  PEAQ_BS_LEVEL(4)
+  PEAQ_BS_LEVEL(8)
 #undef PEAQ_BS_LEVEL
-  // prefix totals at the last lane of rows 0, 1, 2 carried into the rows behind them
-  const double t0r = read_lane<15>(re), t0i = read_lane<15>(im);
-  const double t1r = fma(rot[4][0], t0r, fma(-rot[4][1], t0i, read_lane<31>(re)));
-  const double t1i = fma(rot[4][0], t0i, fma(rot[4][1], t0r, read_lane<31>(im)));
-  const double t2r = fma(rot[4][0], t1r, fma(-rot[4][1], t1i, read_lane<47>(re)));
-  const double t2i = fma(rot[4][0], t1i, fma(rot[4][1], t1r, read_lane<47>(im)));
+  // what came before a row: v and the totals of the rows in front of it
+  const double t0r = vr + read_lane<15>(ar), t0i = vi + read_lane<15>(ai);
+  const double t1r = t0r + read_lane<31>(ar), t1i = t0i + read_lane<31>(ai);
+  const double t2r = t1r + read_lane<47>(ar), t2i = t1i + read_lane<47>(ai);
   const int row = lane >> 4;
-  const double cr = row == 0 ? 0. : row == 1 ? t0r : row == 2 ? t1r : t2r;
-  const double ci = row == 0 ? 0. : row == 1 ? t0i : row == 2 ? t1i : t2i;
-  re = fma(pw_re, cr, fma(-pw_im, ci, re));
-  im = fma(pw_re, ci, fma(pw_im, cr, im));
+  ar += row == 0 ? vr : row == 1 ? t0r : row == 2 ? t1r : t2r;
+  ai += row == 0 ? vi : row == 1 ? t0i : row == 2 ? t1i : t2i;
+  re = fma(pr, ar, -pi * ai);                                         // p (...)
+  im = fma(pr, ai, pi * ar);
 }
 
-// one pair of bands (2 p, 2 p + 1): their filter outputs at the tile's outputs lane = 0 .. 59 -> (yr, yi)[band in pair].
-// The first tile of a launch walks the code twice: pass 0 is the run-in (the outputs BEFORE the tile, lane l <->
-// output l - 64: enter rows only, nothing leaves; band b's sums hold its bs_whole[b] <= 44 newest whole columns,
-// older outputs do not count; result: V(-1)), pass 1 the tile itself.  One body for both keeps the kernel's code
-// inside the instruction cache -- unrolled, this phase alone was as long as the rest of the kernel and every
-// phase ran a fifth slower.
+// lane N of every row of 16 lanes, in all lanes of the row (v_mov_b64_dpp row_newbcast)
+template <int N>
+__device__ __forceinline__ double row_bcast(double v) {
+  return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + N, 0xF, 0xF, false));
+}
+// eight taps (samples 8 G .. 8 G + 7 of the block) of a window's first block: c = the lane's entry of the group's
+// sixteen coefficients (re, im alternating)
+template <int G>
+__device__ __forceinline__ void bs_left_group(const double* __restrict__ xl, double c, double& sr, double& si) {
+  double x[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = lds_rd(xl + (8 * G + k) * kWinRow);
+#define PEAQ_BS_TAP(K)                             \
+  sr = fma(row_bcast<2 * K>(c), x[K], sr);         \
+  si = fma(row_bcast<2 * K + 1>(c), x[K], si);
+  PEAQ_BS_TAP(0) PEAQ_BS_TAP(1) PEAQ_BS_TAP(2) PEAQ_BS_TAP(3) PEAQ_BS_TAP(4) PEAQ_BS_TAP(5) PEAQ_BS_TAP(6) PEAQ_BS_TAP(7)
+#undef PEAQ_BS_TAP
+}
+
+// one pair of bands (2 p, 2 p + 1): their filter outputs at the tile's outputs lane = 0 .. 59 -> (yr, yi)[band in pair];
+// a holds the pair's A operands on entry and the next pair's on return
 __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* __restrict__ stg, double (*vst)[2],
-                                        const FbTables* __restrict__ fb, int p, bool first_tile, int nvs, int lane,
-                                        double (&yr)[2], double (&yi)[2]) {
+                                        const FbTables* __restrict__ fb, double* __restrict__ hist, int p, bool first_tile,
+                                        int nvs, int lane, double (&a)[8], double (&yr)[2], double (&yi)[2]) {
   const int j = lane & 15, kk = lane >> 4;
-  const int col_head = fb->bs_col_head[p], col_tail = fb->bs_col_tail[p];
+  // the tables' uniform entries travel through the scalar cache (constant address space)
+  kint* t_head = (kint*)(const void*)fb->bs_col_head;
+  kint* t_off = (kint*)(const void*)fb->bs_off_enter;
+  kint* t_left = (kint*)(const void*)fb->bs_col_left;
+  kint* t_q0 = (kint*)(const void*)fb->bs_left_q0;
+  kint* t_whole = (kint*)(const void*)fb->bs_whole;
+  const int col_head = t_head[p];
+  // the history of the pair's twelve rows: lane i < J holds enter(i - J); requested first, used after the matrix work
+  double h[2][6];
+  double4 cl[2];                                       // the first blocks' coefficients (bs_left)
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    const int b = 2 * p + sub;
+    const bool has = lane < t_whole[b];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) h[sub][r] = has ? hist[(b * 6 + r) * kBsHist + lane] : 0.;
+    cl[sub] = *reinterpret_cast<const double4*>(fb->bs_left[b][j]);
+  }
+  // r^(lane + 1) of the six chains, and r^J through the scalar cache (constant address space): all in flight during
+  // the matrix work (requested where they are used, every chain waited for its own)
+  double pwr[6], pwi[6], rjr[6], rji[6];
+  {
+    kdouble* rk = (kdouble*)(const void*)&fb->bs_rot[6 * p][0][0];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double2 v = *reinterpret_cast<const double2*>(fb->bs_pow[6 * p + c][lane]);
+      pwr[c] = v.x;
+      pwi[c] = v.y;
+      rjr[c] = rk[4 * c + 2];
+      rji[c] = rk[4 * c + 3];
+    }
+  }
   // staging index of accumulator element i (row kk + 4 i: band i >> 1 of the pair, type kk + 4 (i & 1)) of column tile 0
-  int ih[4], it[4];
+  int ih[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int b = 2 * p + (i >> 1), ty = kk + 4 * (i & 1);
-    const int at = (kk + 4 * i) * kStRow + kStOrg + j;
-    ih[i] = at - fb->bs_off_enter[b] - (ty >= 6 ? 1 : 0);
-    it[i] = at - fb->bs_off_leave[b];
+    const int ty = kk + 4 * (i & 1);
+    ih[i] = (kk + 4 * i) * kStRow + kStOrg + j - t_off[2 * p + (i >> 1)] - (ty >= 6 ? 1 : 0);
   }
-#pragma unroll 1
-  for (int pass = first_tile ? 0 : 1; pass < 2; ++pass) {
-    const bool run_in = pass == 0;
+  {
     v4d acc[4];
-    // (run-in: output -1 of a band whose rows sit bs_off_enter <= 2 columns into the tile reads column
-    // col_head + 1 -- the run-in's 64 columns end at col_head + kStRunIn - 1)
-    const int shift = run_in ? kStRunIn : 0;
-    bs_tile(win, fb->bs_coef[p][0][0], run_in ? col_head - 64 + kStRunIn : col_head, lane, acc);
+    bs_tile(win, a, col_head, lane, acc);
+    bs_coef_load(fb, p + 4, lane, a);                  // the wave's next pair (the last one's request is not used)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) stg[ih[i] + shift + 16 * nt] = acc[nt][i];
-    if (!run_in) {
-      bs_tile(win, fb->bs_coef[p][1][0], col_tail, lane, acc);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(&stg[it[i] + 16 * nt], acc[nt][i]);
-    }
-    wave_lds_fence();
-    const int last = run_in ? 63 : nvs - 1;            // the lane whose sums go on (to the tile / to the next tile)
-#pragma unroll 1
-    for (int sub = 0; sub < 2; ++sub) {
-      const bool live = !run_in || lane >= 64 - fb->bs_whole[2 * p + sub];
-      const double* urow = stg + 8 * sub * kStRow + kStOrg + lane;
-      double sr = urow[6 * kStRow], si = urow[7 * kStRow];   // the two edge blocks
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        const int c = 6 * p + 3 * sub + e;
-        double re = live ? urow[2 * e * kStRow] : 0., im = live ? urow[(2 * e + 1) * kStRow] : 0.;
-        // the chain's constants: r^(1, 2, 4, 8, 16) through the scalar cache (the table is read as constant
-        // memory: as ordinary global loads the six chains' constants sat in 120 vector registers and pushed
-        // the kernel's other state into scratch), r^((lane & 15) + 1) per lane
-        const kdouble* rk = (const kdouble*)(const void*)&fb->bs_rot[c][0][0];
-        const double rot[5][2] = {{rk[0], rk[1]}, {rk[2], rk[3]}, {rk[4], rk[5]}, {rk[6], rk[7]}, {rk[8], rk[9]}};
-        const double2 pw = *reinterpret_cast<const double2*>(fb->bs_pow[c][j]);
-        if (lane == 0 && !run_in) {                    // rot V(-1) joins the first output
-          const double vr = vst[c][0], vi = vst[c][1];
-          re = fma(rot[0][0], vr, fma(-rot[0][1], vi, re));
-          im = fma(rot[0][0], vi, fma(rot[0][1], vr, im));
-        }
-        bs_scan(re, im, rot, pw.x, pw.y, lane);
-        const double vr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(re), last),
-                                           __builtin_amdgcn_readlane(__double2loint(re), last));
-        const double vi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(im), last),
-                                           __builtin_amdgcn_readlane(__double2loint(im), last));
-        if (lane == 0) {
-          vst[c][0] = vr;
-          vst[c][1] = vi;
-        }
-        sr += re;
-        si += im;
-      }
-      yr[0] = sub == 0 ? sr : yr[0];
-      yi[0] = sub == 0 ? si : yi[0];
-      yr[1] = sr;                                      // (the second band's pass leaves its own here)
-      yi[1] = si;
-    }
-    wave_lds_fence();                                  // the next tiles overwrite the staging rows
+      for (int i = 0; i < 4; ++i) stg[ih[i] + 16 * nt] = acc[nt][i];
   }
+  wave_lds_fence();
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    const int b = 2 * p + sub, J = t_whole[b];
+    const double* urow = stg + 8 * sub * kStRow + kStOrg + lane;
+    // the block the window starts in: its samples inside the window (from q0 on) x the filter's own coefficients
+    double sr = urow[6 * kStRow], si = urow[7 * kStRow];     // ... on top of the block it ends in
+    {
+      const double* xl = win + t_left[b] + lane;
+      const int g0 = t_q0[b] >> 3;                     // (whole groups of eight in front of the window are skipped)
+      if (g0 <= 0) bs_left_group<0>(xl, cl[sub].x, sr, si);
+      if (g0 <= 1) bs_left_group<1>(xl, cl[sub].y, sr, si);
+      if (g0 <= 2) bs_left_group<2>(xl, cl[sub].z, sr, si);
+      bs_left_group<3>(xl, cl[sub].w, sr, si);
+    }
+    double hn[6];                                      // what the history will hold after this tile
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int c = 3 * sub + e;
+      double vr, vi;                                   // V(-1)
+      if (first_tile) {                                // from the history: lane J - 1 of its sums
+        double ar = h[sub][2 * e], ai = h[sub][2 * e + 1];
+        bs_chain(ar, ai, 0., 0., pwr[c], pwi[c], lane);
+        vr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ar), J - 1),
+                              __builtin_amdgcn_readlane(__double2loint(ar), J - 1));
+        vi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ai), J - 1),
+                              __builtin_amdgcn_readlane(__double2loint(ai), J - 1));
+      } else {
+        vr = vst[6 * p + c][0];
+        vi = vst[6 * p + c][1];
+      }
+      // enter(t) - rot^J enter(t - J)
+      const bool in_tile = lane >= J;
+      const double er = urow[2 * e * kStRow], ei = urow[(2 * e + 1) * kStRow];
+      const double pr = in_tile ? urow[2 * e * kStRow - J] : h[sub][2 * e];
+      const double pi = in_tile ? urow[(2 * e + 1) * kStRow - J] : h[sub][2 * e + 1];
+      double re = fma(-rjr[c], pr, fma(rji[c], pi, er));
+      double im = fma(-rjr[c], pi, fma(-rji[c], pr, ei));
+      bs_chain(re, im, vr, vi, pwr[c], pwi[c], lane);
+      // the sums after the tile's last valid output go on to the next tile
+      const double wr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(re), nvs - 1),
+                                         __builtin_amdgcn_readlane(__double2loint(re), nvs - 1));
+      const double wi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(im), nvs - 1),
+                                         __builtin_amdgcn_readlane(__double2loint(im), nvs - 1));
+      if (lane == 0) {
+        vst[6 * p + c][0] = wr;
+        vst[6 * p + c][1] = wi;
+      }
+      sr += re;
+      si += im;
+      // history: lane i < J <- enter(nvs - J + i)
+      const int src = nvs - J + lane;
+      hn[2 * e] = urow[2 * e * kStRow + (src >= 0 ? src : 0) - lane];
+      hn[2 * e + 1] = urow[(2 * e + 1) * kStRow + (src >= 0 ? src : 0) - lane];
+    }
+    if (nvs < J) {                                     // a short tile (the last of a launch): part of the old history stays
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double old = __shfl(h[sub][r], lane + nvs, 64);
+        hn[r] = nvs - J + lane >= 0 ? hn[r] : old;
+      }
+    }
+    if (lane < J) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) hist[(b * 6 + r) * kBsHist + lane] = hn[r];
+    }
+    yr[sub] = sr;
+    yi[sub] = si;
+  }
+  wave_lds_fence();                                    // the next pair's tile overwrites the staging rows
 }
 
 // The FP32 instruction's loop, trimmed to what the matrix pipe needs per K step: four ds_read2_b32 (two
@@ -928,9 +993,6 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
 
   constexpr int kKeep = kWin - kTileSub * 32;                       // 1425 samples shared by consecutive tiles
   constexpr int kPre = (kWin - kKeep + 255) / 256;                  // new samples per thread (8)
-  double pre[kPre];
-#pragma unroll
-  for (int q = 0; q < kPre; ++q) pre[q] = 0.;
 
 #ifdef PEAQ_FB_PROFILE
   unsigned long long prof_t_ = __builtin_readcyclecounter();
@@ -943,6 +1005,9 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     int tid_v = tid_k, lane_v = lane_k, wv_s = wv_k;
     asm volatile("" : "+v"(tid_v), "+v"(lane_v), "+s"(wv_s));
     const int tid = tid_v, lane = lane_v, wv = wv_s;
+    double pre[kPre];                                // the next tile's new samples on their way from HBM to the window
+#pragma unroll
+    for (int q = 0; q < kPre; ++q) pre[q] = 0.;
     const unsigned nvb = min((unsigned)kTileBlocks, nb_mine - b0);   // valid blocks in this tile
 #ifdef PEAQ_FB_PROFILE
     if (lane == 0 && (blockIdx.x & 15) == 5) atomicAdd(&g_fb_prof[64 + wv], 1ull);
@@ -964,13 +1029,9 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         }
       const int avail = (int)min((size_t)kWin, row_valid);
       for (int wdx = tid; wdx < kWin; wdx += 256) sh.win.put(wdx, wdx < avail ? row[wdx] : 0., xs);
-    } else {
-#pragma unroll
-      for (int q = 0; q < kPre; ++q) {
-        const int wdx = kKeep + tid + 256 * q;
-        if (wdx < kWin) sh.win.put(wdx, pre[q], xs);
-      }
-    }
+    }                                                // (later tiles: the previous tile has already put its successor's samples)
+    double bs_a[sizeof(WT) == 8 ? 8 : 1];              // FP64 engine: A operands of the wave's first pair, requested
+    if constexpr (sizeof(WT) == 8) bs_coef_load(fb, wv, lane, bs_a);   // in front of the barrier
     if constexpr (sizeof(WT) != 8) {
       double2* az = reinterpret_cast<double2*>(&sh.a.re[0][0]);
       for (int i = tid; i < kFbBands * kACols; i += 256) az[i] = make_double2(0., 0.);
@@ -986,7 +1047,8 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
 #pragma unroll 1
       for (int q = 0; q < 3; ++q) {
         double pr[2], pi[2];
-        bs_pair(reinterpret_cast<const double*>(sh.win.v), stg, sh.vst, fb, wv + 4 * q, b0 == 0, nvs, lane, pr, pi);
+        bs_pair(reinterpret_cast<const double*>(sh.win.v), stg, sh.vst, fb, &st->bs_hist[0][0][0], wv + 4 * q, b0 == 0, nvs,
+                lane, bs_a, pr, pi);
 #pragma unroll
         for (int k = 0; k < 3; ++k)                    // (uniform selects: the loop is not unrolled, y stays in registers)
 #pragma unroll
@@ -1044,18 +1106,24 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     FB_MARK(3);
     // ---- the next tile's window: nobody reads this tile's any more.  Its last 45 columns become
     // the next tile's first 45 (a tile advances by 60 columns = 1920 samples); the new samples are
-    // requested now and land in registers while phases 2b..5 run ---------------------------------------
-    if (b0 + kTileBlocks < nb_mine) {
-      sh.win.shift(tid);
-      const size_t first = (size_t)(b0 + kTileBlocks) * kFbFrame;    // row index of the next window's u = 0
-      const double* src = row + first;
-      const int avail = (int)min((size_t)kWin, row_valid - first);
+    // requested further down (request_next) and land in registers while the remaining phases run ----------
+    if (b0 + kTileBlocks < nb_mine) sh.win.shift(tid);
+    auto request_next = [&]() {
+      if (b0 + kTileBlocks < nb_mine) {
+        const size_t first = (size_t)(b0 + kTileBlocks) * kFbFrame;  // row index of the next window's u = 0
+        const double* src = row + first;
+        const int avail = (int)min((size_t)kWin, row_valid - first);
 #pragma unroll
-      for (int q = 0; q < kPre; ++q) {
-        const int wdx = kKeep + tid + 256 * q;
-        pre[q] = wdx < avail ? src[wdx] : 0.;
+        for (int q = 0; q < kPre; ++q) {
+          const int wdx = kKeep + tid + 256 * q;
+          pre[q] = wdx < avail ? src[wdx] : 0.;
+        }
       }
-    }
+    };
+    // (the reduced-precision engine has the registers to keep them through the spreading; in the FP64 engine's
+    // kernel they would be written to scratch memory as they arrive -- the wave waits for them HERE, reads them back in
+    // the next tile's phase 0 -- so it asks for them after the spreading, with three phases left to cover the latency)
+    if constexpr (sizeof(WT) != 8) request_next();
     FB_MARK(4);
     // ---- phase 2b: level-dependent upward spreading (fbearmodel.c:327-349).  The slope
     // filter runs along time = along the lanes (inclusive scan with the carried-in state);
@@ -1123,6 +1191,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
       }
     }
     __syncthreads();
+    if constexpr (sizeof(WT) == 8) request_next();
     FB_MARK(8);
     // ---- phase 4: rectification + backward masking at block rate (fbearmodel.c:357-382), wave-local: a
     // wave takes the ten bands it carried through phase 2, first E0 = re^2 + im^2 for all time points (lane =
@@ -1184,6 +1253,15 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
 #ifdef PEAQ_DEV_DUMP_FIR
     PEAQ_DEV_DUMP_FIR_WRITE
 #endif
+    // the next tile's new samples have arrived: into the window (its old columns 45.. are dead since the shift; the
+    // barrier of the next tile's phase 0 stands between these writes and the filters)
+    if (b0 + kTileBlocks < nb_mine) {
+#pragma unroll
+      for (int q = 0; q < kPre; ++q) {
+        const int wdx = kKeep + tid + 256 * q;
+        if (wdx < kWin) sh.win.put(wdx, pre[q], xs);
+      }
+    }
     FB_MARK(12);
   }
   __syncthreads();

@@ -289,13 +289,10 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
     for (int p = 0; p < kBsPairs; ++p) {
       const int b0 = 2 * p, b1 = 2 * p + 1;
       fb.bs_col_head[p] = std::min(cR[b0], cR[b1]) - 1;
-      fb.bs_col_tail[p] = std::min(cL[b0], cL[b1]);
       for (int b = b0; b <= b1; ++b) {
         fb.bs_off_enter[b] = cR[b] - 1 - fb.bs_col_head[p];
-        fb.bs_off_leave[b] = cL[b] - fb.bs_col_tail[p];
         // the kernel's tiles span 64 columns for 60 outputs, an edge row sits one column beyond its enter rows
-        if (fb.bs_off_enter[b] < 0 || fb.bs_off_enter[b] > 2 || fb.bs_off_leave[b] < 0 || fb.bs_off_leave[b] > 3)
-          std::abort();
+        if (fb.bs_off_enter[b] < 0 || fb.bs_off_enter[b] > 2) std::abort();
       }
     }
     for (int b = 0; b < kBsBands; ++b) {
@@ -312,27 +309,31 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
         vr = fb.h_re[fb.coef_off[b] + n];
         vi = m == 0 ? 0. : (m > 0 ? fb.h_im[fb.coef_off[b] + n] : -fb.h_im[fb.coef_off[b] + n]);
       };
-      for (int which = 0; which < 2; ++which)            // 0 = head tile (enter, right edge), 1 = tail tile (leave, left edge)
-        for (int q = 0; q < 32; ++q) {
-          const int c_sum = which == 0 ? cR[b] - 1 : cL[b];      // column (relative to t) of the three-exponential rows
-          const int c_own = which == 0 ? cR[b] : cL[b];          // ... of the edge row
-          double row[8];
-          for (int i = 0; i < 3; ++i) {
-            const long double ph = wi[i] * (long double)(32 * c_sum + q - 727);
-            const long double sgn = which == 0 ? 1.0L : -1.0L;   // the leaving block is subtracted
-            row[2 * i] = (double)(sgn * gi[i] * std::cos(ph));
-            row[2 * i + 1] = (double)(-sgn * gi[i] * std::sin(ph));
-          }
-          own(32 * c_own + q - 727, row[6], row[7]);
-          for (int ty = 0; ty < 8; ++ty) fb.bs_coef[p][which][q / 4][(8 * sub + ty) + 16 * (q & 3)] = row[ty];
+      fb.bs_col_left[b] = cL[b];
+      fb.bs_left_q0[b] = (728 - half) & 31;
+      for (int q = 0; q < 32; ++q) {
+        double row[8];
+        for (int i = 0; i < 3; ++i) {                      // a block enters the running sums as column cR - 1
+          const long double ph = wi[i] * (long double)(32 * (cR[b] - 1) + q - 727);
+          row[2 * i] = (double)(gi[i] * std::cos(ph));
+          row[2 * i + 1] = (double)(-gi[i] * std::sin(ph));
         }
+        own(32 * cR[b] + q - 727, row[6], row[7]);
+        for (int ty = 0; ty < 8; ++ty) fb.bs_coef[p][q / 4][(8 * sub + ty) + 16 * (q & 3)] = row[ty];
+        {
+          double lr, li;
+          own(32 * cL[b] + q - 727, lr, li);
+          fb.bs_left[b][(2 * q) & 15][(2 * q) >> 4] = lr;
+          fb.bs_left[b][(2 * q + 1) & 15][(2 * q + 1) >> 4] = li;
+        }
+      }
       for (int i = 0; i < 3; ++i) {
-        for (int k = 0; k < 5; ++k) {
-          const long double ph = 32.0L * wi[i] * (long double)(1 << k);
+        for (int k = 0; k < 2; ++k) {
+          const long double ph = 32.0L * wi[i] * (long double)(k == 0 ? 1 : fb.bs_whole[b]);
           fb.bs_rot[3 * b + i][k][0] = (double)std::cos(ph);
           fb.bs_rot[3 * b + i][k][1] = (double)std::sin(ph);
         }
-        for (int l = 0; l < 16; ++l) {
+        for (int l = 0; l < 64; ++l) {
           const long double ph = 32.0L * wi[i] * (long double)(l + 1);
           fb.bs_pow[3 * b + i][l][0] = (double)std::cos(ph);
           fb.bs_pow[3 * b + i][l][1] = (double)std::sin(ph);
@@ -438,24 +439,29 @@ double fb_tables_selfcheck() {
     }
     std::vector<double> yr(kOut, 0.), yi(kOut, 0.);
     if (b < kBsBands) {
-      const int p = b / 2, sub = b & 1;
-      auto row_dot = [&](int which, int ty, int col) {     // one row of the pair's head / tail tile on window column col
+      const int p = b / 2, sub = b & 1, J = fb.bs_whole[b];
+      auto row_dot = [&](int ty, int col) {                // one row of the pair's tile on window column col
         double acc = 0.;
         for (int q = 0; q < 32; ++q)
-          acc += fb.bs_coef[p][which][q / 4][(8 * sub + ty) + 16 * (q & 3)] * (col >= 0 ? x[32 * col + q] : 0.);
+          acc += fb.bs_coef[p][q / 4][(8 * sub + ty) + 16 * (q & 3)] * (col >= 0 ? x[32 * col + q] : 0.);
         return acc;
       };
       for (int i = 0; i < 3; ++i) {
-        const double rr = fb.bs_rot[3 * b + i][0][0], ri = fb.bs_rot[3 * b + i][0][1];
+        const double (&rot)[2][2] = fb.bs_rot[3 * b + i];
+        std::vector<double> er(kOut + J), ei(kOut + J);    // enter values of the outputs -J .. kOut - 1
+        for (int t = -J; t < kOut; ++t) {
+          const int ch = fb.bs_col_head[p] + t + fb.bs_off_enter[b];
+          er[t + J] = row_dot(2 * i, ch);
+          ei[t + J] = row_dot(2 * i + 1, ch);
+        }
         double vr = 0., vi = 0.;
-        for (int t = -fb.bs_whole[b]; t < kOut; ++t) {     // run-in with nothing leaving, then the tile
-          const int ch = fb.bs_col_head[p] + t + fb.bs_off_enter[b], ct = fb.bs_col_tail[p] + t + fb.bs_off_leave[b];
-          double ur = row_dot(0, 2 * i, ch), ui = row_dot(0, 2 * i + 1, ch);
-          if (t >= 0) {
-            ur += row_dot(1, 2 * i, ct);
-            ui += row_dot(1, 2 * i + 1, ct);
+        for (int t = -J; t < kOut; ++t) {                  // run-in over the history with nothing leaving, then the tile
+          double ur = er[t + J], ui = ei[t + J];
+          if (t >= 0) {                                     // leave(t) = rot^J enter(t - J)
+            ur -= rot[1][0] * er[t] - rot[1][1] * ei[t];
+            ui -= rot[1][0] * ei[t] + rot[1][1] * er[t];
           }
-          const double nr = rr * vr - ri * vi + ur, ni = rr * vi + ri * vr + ui;
+          const double nr = rot[0][0] * vr - rot[0][1] * vi + ur, ni = rot[0][0] * vi + rot[0][1] * vr + ui;
           vr = nr;
           vi = ni;
           if (t >= 0) {
@@ -465,9 +471,13 @@ double fb_tables_selfcheck() {
         }
       }
       for (int t = 0; t < kOut; ++t) {
-        const int ch = fb.bs_col_head[p] + t + fb.bs_off_enter[b] + 1, ct = fb.bs_col_tail[p] + t + fb.bs_off_leave[b];
-        yr[t] += row_dot(0, 6, ch) + row_dot(1, 6, ct);
-        yi[t] += row_dot(0, 7, ch) + row_dot(1, 7, ct);
+        const int ch = fb.bs_col_head[p] + t + fb.bs_off_enter[b] + 1, cl = fb.bs_col_left[b] + t;
+        yr[t] += row_dot(6, ch);
+        yi[t] += row_dot(7, ch);
+        for (int q = fb.bs_left_q0[b]; q < 32; ++q) {
+          yr[t] += fb.bs_left[b][(2 * q) & 15][(2 * q) >> 4] * x[32 * cl + q];
+          yi[t] += fb.bs_left[b][(2 * q + 1) & 15][(2 * q + 1) >> 4] * x[32 * cl + q];
+        }
       }
     } else {
       for (int t = 0; t < kOut; ++t)
