@@ -24,6 +24,13 @@
 #include "peaq_device.h"
 #include "peaq_kernels.h"
 #include "peaq_wave.h"
+#ifdef PEAQ_DEV_PROBES                               // VARIANT builds only (csrc/Makefile): never in the product library
+#define PEAQ_DEV_TU_BACKEND
+#include "dev_probes.inc"
+#endif
+#ifndef PEAQ_DEV_SPIN_INSTEAD_OF_BACKEND
+#define PEAQ_DEV_SPIN_INSTEAD_OF_BACKEND(a, block, stream)
+#endif
 
 namespace peaq {
 
@@ -692,39 +699,10 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
   }
 }
 
-#ifdef PEAQ_BE_SPIN
-// Development probe (tools/ab_basic.sh): what does a co-resident kernel cost the front end?
-// Launched IN PLACE of the back end: PEAQ_AMD_BE_GRID workgroups of two waves run a dependent FP64 chain for
-// PEAQ_AMD_SPIN_ITERS steps in 8 registers; PEAQ_AMD_SPIN_WIDE=1 claims 168 registers without using them.
-// Result (profiles/r03_overlap_probe.txt): one such workgroup per CU slows the front end by 37 % whatever
-// its register footprint -- the cost of a co-resident kernel is its vector-ALU time, not the wave slots it takes.
-template <bool WIDE>
-__global__ __launch_bounds__(128) void spin_kernel(double* out, unsigned iters) {
-  double x = 1. + threadIdx.x * 1e-9, y = 0.5;
-  for (unsigned i = 0; i < iters; ++i) {
-    x = fma(x, 0.999999, y);
-    y = fma(y, 0.5, 1e-9 * x);
-  }
-  if (WIDE) asm volatile("" ::: "v167");
-  if (x == 123.456) out[threadIdx.x] = x + y;
-}
-#endif
-
 hipError_t launch_backend(const BackendArgs& a, unsigned n_pairs, hipStream_t stream) {
   if (n_pairs == 0) return hipSuccess;
   const dim3 block(64 * a.channels);
-#ifdef PEAQ_BE_SPIN
-  {
-    auto env = [](const char* k, long d) { const char* e = std::getenv(k); return e ? std::atol(e) : d; };
-    const dim3 grid((unsigned)env("PEAQ_AMD_BE_GRID", 256));
-    const unsigned iters = (unsigned)env("PEAQ_AMD_SPIN_ITERS", 1000000);
-    if (env("PEAQ_AMD_SPIN_WIDE", 0))
-      hipLaunchKernelGGL(spin_kernel<true>, grid, block, 0, stream, (double*)a.state, iters);
-    else
-      hipLaunchKernelGGL(spin_kernel<false>, grid, block, 0, stream, (double*)a.state, iters);
-    return hipGetLastError();
-  }
-#endif
+  PEAQ_DEV_SPIN_INSTEAD_OF_BACKEND(a, block, stream)
   if (!a.advanced && a.debug)
     hipLaunchKernelGGL((backend_kernel<109, false, true>), dim3(n_pairs), block, 0, stream, a);
   else if (!a.advanced)

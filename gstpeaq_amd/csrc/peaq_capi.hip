@@ -30,6 +30,19 @@
 #include "peaq_device.h"
 #include "peaq_kernels.h"
 #include "peaq_tables.h"
+#ifdef PEAQ_DEV_PROBES                               // VARIANT builds only (csrc/Makefile): never in the product library
+#define PEAQ_DEV_TU_CAPI
+#include "dev_probes.inc"
+#endif
+#ifndef PEAQ_DEV_SERIAL_KERNELS
+#define PEAQ_DEV_SERIAL_KERNELS false
+#endif
+#ifndef PEAQ_DEV_SKIP_BACKEND
+#define PEAQ_DEV_SKIP_BACKEND false
+#endif
+#ifndef PEAQ_DEV_BE_STREAM_PRIO
+#define PEAQ_DEV_BE_STREAM_PRIO(prio, lo, hi)
+#endif
 
 using namespace peaq;
 
@@ -243,8 +256,7 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
     int prio = hi;
-    if (const char* e = std::getenv("PEAQ_AMD_BE_STREAM_PRIO"))   // development: "lo" | "hi" | "none"
-      prio = e[0] == 'l' ? lo : e[0] == 'n' ? (lo + hi) / 2 : hi;
+    PEAQ_DEV_BE_STREAM_PRIO(prio, lo, hi)
     HIP_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio));
   }
   HIP_TRY(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
@@ -435,11 +447,7 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
     const unsigned n_signals = (unsigned)n_pairs * channels * 2;
     const unsigned bc = fb_blocks_per_chunk(n_pairs, channels, max_blocks);
     const size_t row_stride = (size_t)kFbRing + (size_t)bc * kFbFrame;
-#ifdef PEAQ_DEV_SERIAL                                // development: every kernel alone on the device (solo kernel times)
-    const bool piped = false;
-#else
-    const bool piped = max_blocks > bc;               // more than one chunk: 3-stage pipeline, double buffers
-#endif
+    const bool piped = !PEAQ_DEV_SERIAL_KERNELS && max_blocks > bc;   // more than one chunk: 3-stage pipeline, double buffers
     HIP_TRY(c->hp_scratch.reserve((size_t)n_signals * row_stride * sizeof(double)));
     HIP_TRY(c->fb_records.reserve((size_t)n_pairs * bc * channels * kFbRecDoubles * sizeof(double)));
     if (piped) {
@@ -651,11 +659,7 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
     if (!forked) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(forked, stream));
     HIP_TRY(hipStreamWaitEvent(c->aux2, forked, 0));
-#ifdef PEAQ_DEV_SERIAL
-    hipStream_t s_fb = stream;
-#else
-    hipStream_t s_fb = c->aux2;
-#endif
+    hipStream_t s_fb = PEAQ_DEV_SERIAL_KERNELS ? stream : c->aux2;
     const int rc = run_filterbank_path(c, channels, level_db, n_pairs, d_ref, d_test, pair_stride, d_nref, d_ntest,
                                        n_uniform, d_nblocks, max_blocks, s_fb);
     if (rc != PEAQ_OK) return rc;
@@ -716,9 +720,7 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
     HIP_TRY(hipEventRecord(e1, stream));
     HIP_TRY(hipStreamWaitEvent(c->aux, e1, 0));
     HIP_TRY(hipEventRecord(e2, c->aux));
-#ifndef PEAQ_DEV_NO_BACKEND                           // development: what the back end costs the step (results are wrong)
-    HIP_TRY(launch_backend(ba, n_pairs, c->aux));
-#endif
+    if (!PEAQ_DEV_SKIP_BACKEND) HIP_TRY(launch_backend(ba, n_pairs, c->aux));
     HIP_TRY(hipEventRecord(e3, c->aux));
     back_done[chunk & 1] = e3;
     c->spans.push_back({e0, e1, 0});

@@ -97,6 +97,42 @@ def test_frontend_records_match_oracle(gpu, bands, case):
     np.testing.assert_allclose(got[:, :, 565:567], exp[:, :, 565:567], rtol=1e-12, atol=0, err_msg="energies")
 
 
+@pytest.mark.parametrize("bands", [109, 55])
+def test_energy_threshold_at_the_boundary(gpu, bands):
+    """fftearmodel.c:508-514: a frame counts for the error harmonic structure when the energy of its second half --
+    squares formed in SINGLE precision, summed in double -- reaches 8000 / 32768^2 = 125 * 2^-24.  The kernel sums the
+    squares as a tree, the reference in order; frames whose partial sums are all exact in double make the order
+    irrelevant and put the threshold itself to the test: 125 samples of 2^-12 give exactly the threshold (flag set);
+    one of them an ulp of single precision smaller, 2^-46 below it (flag clear); an ulp larger, 2^-46 above (set).
+    (A frame that sits on the threshold to the last bit of a sum that is NOT exact can still come out differently
+    from the reference's loop: DESIGN.md 4, "not bit-exact by design".)"""
+    import torch
+    import gstpeaq_amd
+    n_frames = 5
+    n = 1024 * (n_frames + 1)
+    base = np.float32(2.0 ** -12)
+    variants = {
+        "exact": (base, True),
+        "below": (np.float32(base * np.float32(1 - 2.0 ** -23)), False),
+        "above": (np.float32(base * np.float32(1 + 2.0 ** -23)), True),
+    }
+    for name, (special, expect) in variants.items():
+        sig = np.zeros((n, 1), np.float32)
+        # frame 2 covers samples 2048 .. 4095; its second half is 3072 .. 4095: 125 scattered samples
+        idx = 3072 + (np.arange(125) * 8 + 3)
+        sig[idx, 0] = base
+        sig[idx[77], 0] = special
+        ref = torch.from_numpy(sig).cuda()
+        got = gstpeaq_amd.debug_frontend(gpu.ctx(), bands, ref, ref, n_frames)
+        exp = oracle_records(bands, sig, sig, n_frames)
+        assert np.array_equal(got[:, :, 563:565], exp[:, :, 563:565]), name
+        # bit 1 of the flag words = energy threshold reached (ref, test)
+        flags = got[:, 0, 563].astype(int)
+        assert bool(flags[2] & 2) == expect, (name, flags)
+        # the frames before and after hold fewer of the samples: below the threshold
+        assert not (flags[0] & 2) and not (flags[4] & 2), (name, flags)
+
+
 @pytest.mark.parametrize("bpl", [320, 7])
 @pytest.mark.parametrize("case", [
     dict(kind="synth", seed=5, channels=1, n=30000),
