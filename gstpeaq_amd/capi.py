@@ -396,15 +396,17 @@ def debug_filterbank(ctx, ref, test, n_blocks, blocks_per_launch=320, playback_l
     return out
 
 
-BACKEND_DEBUG_DOUBLES = 904
+BACKEND_DEBUG_DOUBLES = 912
 BACKEND_DEBUG_VECTORS = ["exc_ref", "exc_test", "adapted_ref", "adapted_test", "mod_ref", "mod_test",
                          "avgloud_ref", "avgloud_test"]
+BACKEND_DEBUG_MOVS = ["moddiff1", "moddiff2", "tempwt", "noiseloud", "nmr_mean", "nmr_max", "p_detect", "steps"]
 
 
 def debug_backend(ctx, records):
     """Stage-level access to the stateful back end (basic version, fresh state).
     records: np [frames, channels, 576] front-end records (from debug_frontend, or hand-built).
-    -> (dict name -> np [frames, channels, 109] for BACKEND_DEBUG_VECTORS plus 'loudness' [frames, channels, 2],
+    -> (dict name -> np [frames, channels, 109] for BACKEND_DEBUG_VECTORS plus 'loudness' [frames, channels, 2] and
+        'mov' (dict name -> np [frames, channels] for BACKEND_DEBUG_MOVS; the last two: channel 0 only),
         result dict after the last frame)"""
     rec = np.ascontiguousarray(records, dtype=np.float64)
     n_frames, channels, width = rec.shape
@@ -416,4 +418,6 @@ def debug_backend(ctx, records):
                                     res.ctypes.data_as(dp)))
     d = {name: out[:, :, 112 * i: 112 * i + 109] for i, name in enumerate(BACKEND_DEBUG_VECTORS)}
     d["loudness"] = out[:, :, 896:898]
+    # the MOV layer's per-frame values before accumulation (include/peaq_amd.h, PEAQ_DEBUG_BACKEND_DOUBLES)
+    d["mov"] = dict(zip(BACKEND_DEBUG_MOVS, np.moveaxis(out[:, :, 904:912], 2, 0)))
     return d, _result_dict(res, False)

@@ -588,19 +588,31 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
         const int g = sh.gate[0] | (channels == 2 ? sh.gate[1] : 0);
         if (g) loud_reached = frame;
       }
+      double* __restrict__ dmov =                    // debug instantiation: this (frame, channel)'s MOV values
+          DBG ? a.debug + ((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels + chan) * kDbgDoubles + kDbgMov
+              : nullptr;
       // ---- modulation difference (gstpeaq.c:871-877) --------------------------------
-      if (frame >= 24) {
+      if (DBG || frame >= 24) {
         double d1, d2, wt;
         mod_difference<NB, SLOTS>(bl, bt, 100., mr, mt, mdr[1], d1, d2, wt);
         d1 *= 100. / NB;
         d2 *= 100. / NB;
-        route(MB_AVGMOD1, d1, wt);
-        route(MB_AVGMOD2, d2, wt);
-        route(MB_WINMOD, d1, 1.);
+        if (frame >= 24) {
+          route(MB_AVGMOD1, d1, wt);
+          route(MB_AVGMOD2, d2, wt);
+          route(MB_WINMOD, d1, 1.);
+        }
+        if (DBG && lane == 0) {
+          dmov[0] = d1;
+          dmov[1] = d2;
+          dmov[2] = wt;
+        }
       }
       // ---- noise loudness (gstpeaq.c:880-886; unsigned compare with UINT_MAX sentinel)
-      if (frame >= 24 && frame - 3 >= loud_reached) {
-        route(MB_NOISELOUD, noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 0.5, 0., mr, mt, ad_ref, ad_test), 1.);
+      if (DBG || (frame >= 24 && frame - 3 >= loud_reached)) {
+        const double nl = noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 0.5, 0., mr, mt, ad_ref, ad_test);
+        if (frame >= 24 && frame - 3 >= loud_reached) route(MB_NOISELOUD, nl, 1.);
+        if (DBG && lane == 0) dmov[3] = nl;
       }
       // ---- bandwidth (movs.c:797-807) ------------------------------------------------------
       {
@@ -624,6 +636,12 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
       }
       nsum = wave_sum(nsum) / NB;
       nmax = wave_max(nmax);
+      if (DBG && lane == 0) {
+        double* __restrict__ d =
+            a.debug + ((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels + chan) * kDbgDoubles + kDbgMov;
+        d[4] = nsum;
+        d[5] = nmax;
+      }
       if (!ADV) {
         route(MB_NMR, nsum, 1.);                                    // MODE_AVG_LOG
         route(MB_RELDIST, nmax > 1.41253754462275 ? 1. : 0., 1.);
@@ -654,6 +672,12 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
       }
       const double p_bin = 1. - wave_prod(pprod);
       qsum = wave_sum(qsum);
+      if (DBG && lane == 0) {
+        double* __restrict__ d =
+            a.debug + ((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels) * kDbgDoubles + kDbgMov;
+        d[6] = p_bin;
+        d[7] = qsum;
+      }
       if (p_bin > 0.5) route(MB_ADB, qsum, 1.);
       route(MB_MFPD, p_bin, 1.);
     }

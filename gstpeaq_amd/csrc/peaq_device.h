@@ -223,7 +223,13 @@ constexpr int kDbgAvgLoudRef   = 6 * kBandStride;   // average loudness (modpatt
 constexpr int kDbgAvgLoudTest  = 7 * kBandStride;
 constexpr int kDbgLoudnessRef  = 8 * kBandStride;   // total loudness while the gate is closed (earmodel.c:891-907)
 constexpr int kDbgLoudnessTest = 8 * kBandStride + 1;
-constexpr int kDbgDoubles      = 8 * kBandStride + 8;   // == PEAQ_DEBUG_BACKEND_DOUBLES
+// the MOV layer's per-frame values BEFORE accumulation, computed for every frame in the debug instantiation
+// (the accumulators only see them when the gates of gstpeaq.c:871,880-881 are open):
+constexpr int kDbgMov          = 8 * kBandStride + 8;   // + 0 ModDiff1, 1 ModDiff2, 2 TempWt (movs.c:205-254), 3 noise
+                                                        // loudness (:354-371), 4 mean and 5 maximum of the band NMRs
+                                                        // (:971-1023); channel 0 only: 6 detection probability, 7 steps
+                                                        // above threshold (:1224-1276)
+constexpr int kDbgDoubles      = 8 * kBandStride + 16;  // == PEAQ_DEBUG_BACKEND_DOUBLES
 
 // filter-bank record per (pair, block, channel): unsmeared/excitation of both
 // signals + above-threshold flag

@@ -267,11 +267,15 @@ int peaq_debug_filterbank (peaq_ctx *ctx, int channels, double playback_level_db
  *   8 band vectors of 112 -- excitation ref/test (fftearmodel.c:496-504), spectrally
  *   adapted ref/test (leveladapter.c:243-340), modulation ref/test and average
  *   loudness ref/test (modpatt.c:223-251) -- then total loudness ref, test
- *   (earmodel.c:891-907; only written while the loudness gate is still closed).
+ *   (earmodel.c:891-907; only written while the loudness gate is still closed), six unused, and then the MOV
+ *   layer's values of this frame BEFORE accumulation, computed for every frame whether or not the gates of
+ *   gstpeaq.c:871,880-881 let the accumulators see them: ModDiff1, ModDiff2, TempWt (movs.c:205-254), noise
+ *   loudness (:354-371), mean and maximum of the band noise-to-mask ratios (:971-1023) and, with channel 0
+ *   only, detection probability and steps above threshold of the frame (:1224-1276).
  * `result` (may be NULL) receives the MOVs/DI/ODG after the last frame.
  * Pins the HIP pattern layer against the reference's own known-answer vectors
  * (testpeaq.c:433-599,748-810). */
-#define PEAQ_DEBUG_BACKEND_DOUBLES 904
+#define PEAQ_DEBUG_BACKEND_DOUBLES 912
 int peaq_debug_backend (peaq_ctx *ctx, int channels, int n_frames, const double *host_records,
                         double *host_out, peaq_result *result);
 

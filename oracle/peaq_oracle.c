@@ -796,6 +796,10 @@ struct orc_session {
   orc_modproc ref_mod[2], test_mod[2];
   orc_movaccum acc[MB_COUNT];
   double sig_energy, noise_energy;
+  /* test hook (orc_flat_mov_trace): per FFT frame and channel the basic version's MOV values before
+   * accumulation, whether or not the gates of gstpeaq.c:871,880-881 are open */
+  double *trace;
+  unsigned trace_frames;
 };
 
 static int
@@ -848,27 +852,40 @@ noise_loudness (const orc_bands *b, double alpha, double thres_fac, double s0, d
 }
 
 static void
+moddiff_of_channel (const orc_session *s, const orc_bands *b, int c, double lev_wt, int rms,
+                    double *d1_out, double *d2_out, double *wt_out)
+{
+  /* movs.c:205-254, one channel */
+  const double *mr = s->ref_mod[c].modulation, *mt = s->test_mod[c].modulation;
+  const double *lr = s->ref_mod[c].filt_loud;
+  double d1 = 0., d2 = 0., wt = 0.;
+  int i;
+  for (i = 0; i < b->bands; i++) {
+    double diff = fabs (mr[i] - mt[i]);
+    d1 += diff / (1. + mr[i]);
+    d2 += (mt[i] >= mr[i] ? 1. : .1) * diff / (0.01 + mr[i]);
+    wt += lr[i] / (lr[i] + lev_wt * pow (b->internal_noise[i], 0.3));
+  }
+  if (rms)
+    d1 *= 100. / sqrt (b->bands);
+  else
+    d1 *= 100. / b->bands;
+  d2 *= 100. / b->bands;
+  *d1_out = d1;
+  *d2_out = d2;
+  *wt_out = wt;
+}
+
+static void
 mov_moddiff (orc_session *s, const orc_bands *b, orc_movaccum *a1, orc_movaccum *a2,
              orc_movaccum *awin)
 {
   /* movs.c:205-254 */
   double lev_wt = a2 ? 100. : 1.;
-  int c, i;
+  int c;
   for (c = 0; c < a1->channels; c++) {
-    const double *mr = s->ref_mod[c].modulation, *mt = s->test_mod[c].modulation;
-    const double *lr = s->ref_mod[c].filt_loud;
-    double d1 = 0., d2 = 0., wt = 0.;
-    for (i = 0; i < b->bands; i++) {
-      double diff = fabs (mr[i] - mt[i]);
-      d1 += diff / (1. + mr[i]);
-      d2 += (mt[i] >= mr[i] ? 1. : .1) * diff / (0.01 + mr[i]);
-      wt += lr[i] / (lr[i] + lev_wt * pow (b->internal_noise[i], 0.3));
-    }
-    if (a1->mode == ORC_RMS)
-      d1 *= 100. / sqrt (b->bands);
-    else
-      d1 *= 100. / b->bands;
-    d2 *= 100. / b->bands;
+    double d1, d2, wt;
+    moddiff_of_channel (s, b, c, lev_wt, a1->mode == ORC_RMS, &d1, &d2, &wt);
     orc_acc_add (a1, c, d1, wt);
     if (a2)
       orc_acc_add (a2, c, d2, wt);
@@ -929,23 +946,33 @@ noise_in_bands (const orc_fftmodel *m, const double *wr, const double *wt, doubl
 }
 
 static void
+nmr_of_channel (const orc_session *s, int c, double *mean_out, double *max_out)
+{
+  /* movs.c:987-1012, one channel: weighted spectra, smeared ref excitation */
+  const orc_fftmodel *m = &s->fftm;
+  const double *wr = s->ref_fft_st[c].weighted, *wt = s->test_fft_st[c].weighted;
+  double nib[ORC_MAXBANDS], nmr = 0., nmr_max = 0.;
+  int i, nb = m->b.bands;
+  noise_in_bands (m, wr, wt, nib);
+  for (i = 0; i < nb; i++) {
+    double mask = s->ref_fft_st[c].excitation[i] / m->mask_diff[i];
+    double r = nib[i] / mask;
+    nmr += r;
+    if (r > nmr_max)
+      nmr_max = r;
+  }
+  *mean_out = nmr / nb;
+  *max_out = nmr_max;
+}
+
+static void
 mov_nmr (orc_session *s, orc_movaccum *anmr, orc_movaccum *arel)
 {
-  /* movs.c:971-1023: weighted spectra, smeared ref excitation */
-  const orc_fftmodel *m = &s->fftm;
-  int c, i, nb = m->b.bands;
+  /* movs.c:971-1023 */
+  int c;
   for (c = 0; c < anmr->channels; c++) {
-    const double *wr = s->ref_fft_st[c].weighted, *wt = s->test_fft_st[c].weighted;
-    double nib[ORC_MAXBANDS], nmr = 0., nmr_max = 0.;
-    noise_in_bands (m, wr, wt, nib);
-    for (i = 0; i < nb; i++) {
-      double mask = s->ref_fft_st[c].excitation[i] / m->mask_diff[i];
-      double r = nib[i] / mask;
-      nmr += r;
-      if (r > nmr_max)
-        nmr_max = r;
-    }
-    nmr /= nb;
+    double nmr, nmr_max;
+    nmr_of_channel (s, c, &nmr, &nmr_max);
     if (anmr->mode == ORC_AVG_LOG)
       orc_acc_add (anmr, c, nmr, 1.);
     else
@@ -956,9 +983,9 @@ mov_nmr (orc_session *s, orc_movaccum *anmr, orc_movaccum *arel)
 }
 
 static void
-mov_prob_detect (orc_session *s, orc_movaccum *aadb, orc_movaccum *amfpd)
+prob_detect_of_frame (const orc_session *s, double *p_out, double *q_out)
 {
-  /* movs.c:1224-1276 */
+  /* movs.c:1224-1270 */
   int nb = s->fftm.b.bands, c, i;
   double p_bin = 1., q_bin = 0.;
   for (i = 0; i < nb; i++) {
@@ -982,7 +1009,16 @@ mov_prob_detect (orc_session *s, orc_movaccum *aadb, orc_movaccum *amfpd)
     p_bin *= 1. - p_band;
     q_bin += q_band;
   }
-  p_bin = 1. - p_bin;
+  *p_out = 1. - p_bin;
+  *q_out = q_bin;
+}
+
+static void
+mov_prob_detect (orc_session *s, orc_movaccum *aadb, orc_movaccum *amfpd)
+{
+  /* movs.c:1271-1276 */
+  double p_bin, q_bin;
+  prob_detect_of_frame (s, &p_bin, &q_bin);
   if (p_bin > 0.5)
     orc_acc_add (aadb, 0, q_bin, 1.);
   orc_acc_add (amfpd, 0, p_bin, 1.);
@@ -1117,6 +1153,16 @@ fft_frame_basic (orc_session *s, const float *ref, const float *test)
   mov_prob_detect (s, &s->acc[MB_ADB], &s->acc[MB_MFPD]);
   mov_ehs (s, &s->acc[MB_EHS]);
   snr_accumulate (s, ref, test, ORC_FFT_FRAME);
+  if (s->trace && s->frame_counter < s->trace_frames)
+    for (c = 0; c < s->channels; c++) {
+      double *t = s->trace + ((size_t) s->frame_counter * s->channels + c) * 8;
+      moddiff_of_channel (s, b, c, 100., 0, &t[0], &t[1], &t[2]);
+      t[3] = noise_loudness (b, 1.5, 0.15, 0.5, 0., s->ref_mod[c].modulation, s->test_mod[c].modulation,
+                             s->lev[c].adapted_ref, s->lev[c].adapted_test);
+      nmr_of_channel (s, c, &t[4], &t[5]);
+      if (c == 0)
+        prob_detect_of_frame (s, &t[6], &t[7]);
+    }
   s->frame_counter++;
 }
 
@@ -1362,6 +1408,22 @@ orc_run_pair (int advanced, int channels, double level_db,
 /* ======================================================================== */
 /* flat entry points for ctypes (tests only)                                  */
 /* ======================================================================== */
+
+/* Test entry point: one pair through a basic-version session; out[frame][channel][8] = ModDiff1, ModDiff2,
+ * TempWt (movs.c:205-254), noise loudness (:354-371), mean and maximum of the band noise-to-mask ratios
+ * (:971-1023) and (channel 0) detection probability and steps above threshold (:1224-1270) of every frame. */
+void
+orc_flat_mov_trace (int channels, double level_db, const float *ref, size_t n_ref, const float *test,
+                    size_t n_test, int n_frames, double *out)
+{
+  orc_session *s = orc_session_new (0, channels, level_db);
+  s->trace = out;
+  s->trace_frames = (unsigned) n_frames;
+  orc_session_push_ref (s, ref, n_ref);
+  orc_session_push_test (s, test, n_test);
+  orc_session_flush (s);
+  orc_session_free (s);
+}
 
 static const orc_bands *
 flat_bands (int bands, orc_fftmodel *fm, orc_fbmodel *bm)

@@ -44,6 +44,7 @@ def lib():
         L.orc_flat_leveladapt.argtypes = [C.c_int, _dp, _dp, C.c_int, _dp, _dp]
         L.orc_flat_modproc.argtypes = [C.c_int, _dp, C.c_int, _dp, _dp]
         L.orc_flat_tables.argtypes = [C.c_int, _dp]
+        L.orc_flat_mov_trace.argtypes = [C.c_int, C.c_double, _fp, C.c_size_t, _fp, C.c_size_t, C.c_int, _dp]
         L.orc_di_basic.restype = C.c_double
         L.orc_di_basic.argtypes = [_dp]
         L.orc_di_advanced.restype = C.c_double
@@ -114,6 +115,21 @@ def run_pair(advanced, ref, test, level=92.0):
     r = s.results()
     s.close()
     return r
+
+
+MOV_TRACE = ["moddiff1", "moddiff2", "tempwt", "noiseloud", "nmr_mean", "nmr_max", "p_detect", "steps"]
+
+
+def mov_trace(ref, test, n_frames, level=92.0):
+    """basic version, one pair: the MOV layer's values of every frame before accumulation
+    -> dict name -> np [frames, channels] (MOV_TRACE; the last two: channel 0 only)"""
+    ref = np.ascontiguousarray(ref, dtype=np.float32)
+    test = np.ascontiguousarray(test, dtype=np.float32)
+    ch = ref.shape[1]
+    out = np.zeros((n_frames, ch, 8))
+    lib().orc_flat_mov_trace(ch, level, _ptr(ref, _fp), ref.shape[0], _ptr(test, _fp), test.shape[0], n_frames,
+                             _ptr(out, _dp))
+    return dict(zip(MOV_TRACE, np.moveaxis(out, 2, 0)))
 
 
 def fftear(bands, x, n_frames, hop, level=92.0):

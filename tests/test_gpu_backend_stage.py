@@ -127,3 +127,42 @@ def test_backend_patterns_match_oracle_per_frame(gpu, case):
     assert res["frames"] == exp["frames"] == n_frames
     np.testing.assert_allclose(res["movs"], exp["movs"], rtol=1e-7, atol=1e-9)
     assert abs(res["odg"] - exp["odg"]) < 1e-6
+
+
+@pytest.mark.parametrize("case", [
+    dict(kind="synth", seed=5, channels=1, n=72000),
+    dict(kind="synth", seed=6, channels=2, n=60000, test_trim=900),
+    dict(kind="synth", seed=1, channels=2, n=60000),             # leading digital silence
+    dict(kind="synth", seed=9, channels=2, n=40000, atten_shift=9),   # around the detector thresholds
+    dict(kind="synth", seed=26, channels=2, n=40000, identical=1),
+    dict(kind="ats", wave_ref="saw", wave_test="triangle", n=65536, channels=1),
+], ids=["mono", "stereo-ragged", "lead-silence", "quiet", "identical", "saw-triangle"])
+def test_mov_values_match_oracle_per_frame(gpu, case):
+    """The MOV layer frame by frame, before the accumulators: modulation differences and their weight
+    (movs.c:205-254), noise loudness (:354-371), mean and maximum of the band noise-to-mask ratios (:971-1023),
+    detection probability and steps above threshold (:1224-1276) -- every frame, also those the gates of
+    gstpeaq.c:871,880-881 keep from the accumulators.  End to end a wrong MOV shows; this says which and where."""
+    import torch
+    import gstpeaq_amd
+    import gstpeaq_amd.capi as capi
+    ref, test = case_defs.make_inputs(case)
+    n = min(len(ref), len(test))
+    ref, test = ref[:n], test[:n]
+    n_frames = (n - 2048) // 1024 + 2           # all full frames + the zero-padded flush frame
+    recs = gstpeaq_amd.debug_frontend(gpu.ctx(), NB, torch.from_numpy(ref).cuda(), torch.from_numpy(test).cuda(),
+                                      n_frames)
+    d, _ = capi.debug_backend(gpu.ctx(), recs)
+    exp = orc.mov_trace(ref, test, n_frames)
+    ch = ref.shape[1]
+    for name in orc.MOV_TRACE:
+        got, want = d["mov"][name], exp[name]
+        if name in ("p_detect", "steps"):
+            got, want = got[:, :1], want[:, :1]
+        # the modulation differences inherit the modulation's cancellation (|L - L_prev| of a stationary signal), the
+        # noise-to-mask ratios the noise spectrum's (Pr - 2 sqrt(Pr Pt) + Pt of nearly equal spectra): 1e-6 there
+        rtol = 1e-6 if name in ("moddiff1", "moddiff2", "nmr_mean", "nmr_max", "noiseloud") else 1e-9
+        if case.get("identical") and name in ("nmr_mean", "nmr_max"):
+            # identical signals: the noise spectrum is what rounding leaves of Pr - 2 sqrt(Pr Pr) + Pr
+            assert np.all(np.abs(got[:, :ch]) < 1e-9) and np.all(np.abs(want[:, :ch]) < 1e-9), name
+            continue
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-12, err_msg=name)
