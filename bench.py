@@ -251,6 +251,13 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # PEAQ_BENCH_DIST_BACKEND=gloo: the N > 1 path with a CPU communicator, every rank on the GPU(s) the box has
+    # (RCCL refuses two ranks on one device) -- how tests/test_gpu_two_ranks.py runs two REAL ranks on a one-GPU
+    # box: shards, seeds, waves, timing reduction and the gather (staged through host memory) are the production
+    # code, only the transport differs.  Default: "nccl" = RCCL over xGMI.
+    backend = os.environ.get("PEAQ_BENCH_DIST_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -259,7 +266,11 @@ def main():
     if world > 1 or os.environ.get("PEAQ_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+    cdev = torch.device("cpu") if backend == "gloo" else dev   # where the collectives' small tensors live
 
     waves_mode = args.waves or world > 1
     pairs_per_gpu = args.pairs or (CONFIG4_PAIRS_PER_GPU if waves_mode else 4096)
@@ -308,7 +319,7 @@ def main():
         return timed, wall, ctx.last_timing()
 
     def reduce_max(x):
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
         if dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -322,6 +333,9 @@ def main():
         gathered = parallel.gather_results(results, world, dist)
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0 and os.environ.get("PEAQ_BENCH_DUMP_RESULTS"):   # tests: the job's result records in pair order
+            import numpy as np
+            np.save(os.environ["PEAQ_BENCH_DUMP_RESULTS"], gathered.cpu().numpy())
         frame_pairs_all = float(gathered[:, 14].sum().item())
         frame_pairs_rank = float(results[:, 14].sum().item())
         return dict(timed=timed, wall=wall, timing=timing, gathered=gathered, fp_all=frame_pairs_all, gather_ms=gather_ms,

@@ -47,6 +47,8 @@ def gather_results(local, world, dist=None):
     import torch
     if dist is None:                      # single process, no communicator
         return local
+    if dist.get_backend() == "gloo":      # CPU communicator (tests; several ranks on ONE GPU): through host memory
+        local = local.cpu()
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)

@@ -1,0 +1,58 @@
+"""The N > 1 path of bench.py with TWO real ranks on the box's one GPU.  RCCL refuses two ranks on one device, so
+the communicator is gloo (PEAQ_BENCH_DIST_BACKEND=gloo, bench.py): shards, per-rank seed offsets, the waves of each
+rank, the all_reduce(MAX) of the timings and the gather of the HIP-produced result records -- staged through host
+memory -- are the production code, only the transport of the collectives differs from the 8-GPU run.  The gathered
+records must equal, bit for bit and in pair order, those of ONE process running the same 192 seeds.
+Needs an MI355X (`-m gpu`)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+COMMON = ["--steps", "1", "--warmup", "1", "--wave-pairs", "64", "--seconds", "2", "--no-advanced"]
+
+
+def run(cmd, env):
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_two_ranks_on_one_gpu_equal_one_process(tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (there is no CPU fallback in the product)")
+    two, one = tmp_path / "two.npy", tmp_path / "one.npy"
+    env2 = dict(os.environ, PEAQ_BENCH_DIST_BACKEND="gloo", PEAQ_BENCH_DUMP_RESULTS=str(two),
+                HSA_ENABLE_IPC_MODE_LEGACY="0")
+    line2 = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                 "--master-addr", "127.0.0.1", "--master-port", "29531", str(ROOT / "bench.py"), "--gpus", "2",
+                 "--pairs", "96"] + COMMON, env2)
+    env1 = dict(os.environ, PEAQ_BENCH_DUMP_RESULTS=str(one))
+    line1 = run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--waves", "--pairs", "192",
+                 "--no-cpu-baseline", "--no-scaling-reference"] + COMMON, env1)
+    a, b = np.load(two), np.load(one)
+    assert a.shape == b.shape == (192, 16)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), "gathered records differ from the one-process run"
+    # pair i carries seed 1 + i: its ODG differs from pair to pair, so equal arrays also mean equal ORDER; and the
+    # second rank's block really came from the other process
+    assert len(np.unique(a[:, 12])) > 150
+    # the N = 2 line
+    cfg = line2["config"]
+    assert line2["n_gpus"] == 2 and cfg["total_pairs"] == 192 and cfg["pairs_per_gpu"] == 96
+    assert cfg["result_gather"] == "gloo all_gather over 2 rank(s)" and cfg["waves_per_step"] == 2
+    assert line2["scaling"] == "weak" and line2["odg_nan"] == 0
+    assert abs(line2["per_gpu_value"] * 2 - line2["value"]) < 1e-6 * line2["value"]
+    assert "scaling_note" in line2 and line2["result_gather_ms"] >= 0
+    # the one-core CPU baseline also at N > 1 (rank 0, after the timed region)
+    cb = line2["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["value"] > 0 and cb["kind"] in ("reference", "port")
+    # 2 s pairs: 93 frame pairs each, both lines
+    assert cfg["frame_pairs_per_pair"] == line1["config"]["frame_pairs_per_pair"] == 93
+    assert line1["odg_mean"] == pytest.approx(line2["odg_mean"], abs=1e-12)
