@@ -115,6 +115,11 @@ def load_library():
     L.peaq_debug_filterbank.argtypes = [vp, C.c_int, C.c_double, vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, dp]
     ip = C.POINTER(C.c_int)
     L.peaq_broker_create.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(vp)]
+    L.peaq_broker_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, C.c_int,
+                                           C.POINTER(vp)]
+    L.peaq_broker_devices.argtypes = [vp]
+    L.peaq_broker_stats_size.argtypes = []
+    L.peaq_broker_stats_size.restype = C.c_size_t
     L.peaq_broker_destroy.argtypes = [vp]
     L.peaq_broker_destroy.restype = None
     L.peaq_broker_open.argtypes = [vp, ip]
@@ -246,12 +251,25 @@ class Session:
 class Broker:
     """Many live sessions (one per hosted `peaq` element), one batched launch per tick."""
 
-    def __init__(self, ctx, channels, max_sessions, playback_level=92.0, advanced=False):
+    def __init__(self, ctx, channels, max_sessions, playback_level=92.0, advanced=False, devices=None, fir_mode=None):
+        """devices = None: one broker on ctx's GPU.  devices = [ordinals]: peaq_broker_create_multi -- one device
+        broker (with a context of its own) per entry, sessions dealt out to the least loaded; ctx only lends the
+        loaded library then."""
         self.ctx, self.channels, self.advanced = ctx, channels, bool(advanced)
         self.L = ctx.L
         self.h = C.c_void_p()
-        _check(self.L.peaq_broker_create(ctx.h, int(bool(advanced)), int(channels), float(playback_level),
-                                         int(max_sessions), C.byref(self.h)))
+        if devices is None:
+            _check(self.L.peaq_broker_create(ctx.h, int(bool(advanced)), int(channels), float(playback_level),
+                                             int(max_sessions), C.byref(self.h)))
+        else:
+            assert self.L.peaq_broker_stats_size() == C.sizeof(_BrokerStats)
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            mode = -1 if fir_mode is None else FIR_MODES[fir_mode]
+            _check(self.L.peaq_broker_create_multi(arr, len(devices), int(bool(advanced)), int(channels),
+                                                   float(playback_level), int(max_sessions), None, mode, C.byref(self.h)))
+
+    def devices(self):
+        return int(self.L.peaq_broker_devices(self.h))
 
     def open(self):
         sid = C.c_int(-1)

@@ -1510,7 +1510,21 @@ struct peaq_broker {
   double parked_host_us = 0.;
   std::vector<BrokerJob> jobs;      // this tick's staging work
   std::unique_ptr<StagePool> stagers;
+  // peaq_broker_create_multi: this broker owns no device; it deals its sessions out to one broker per device
+  // (session id = shard + n_shards * the shard's own id) and forwards every call
+  std::vector<peaq_broker*> shards;
+  std::vector<peaq_ctx*> shard_ctx;
+  std::vector<int> shard_open;      // open sessions per shard (guarded by tick_mu)
 };
+
+static inline bool broker_is_multi(const peaq_broker* b) { return b && !b->shards.empty(); }
+// -> the device broker that owns session `sid` of b, and the session's id there
+static inline peaq_broker* broker_shard_of(peaq_broker* b, int sid, int* local) {
+  const int n = (int)b->shards.size();
+  if (sid < 0 || sid >= b->max_sessions) return nullptr;
+  *local = sid / n;
+  return b->shards[sid % n];
+}
 
 // copies nv[p] samples per pad from the slot's FIFOs at pos[] into staging entry `idx`
 static void broker_stage_copy(const peaq_broker* b, const BrokerSlot& sl, const BrokerStage& st, unsigned idx,
@@ -1830,8 +1844,53 @@ extern "C" int peaq_broker_create(peaq_ctx* c, int advanced, int channels, doubl
   return PEAQ_OK;
 }
 
+extern "C" int peaq_broker_create_multi(const int* devices, int n_devices, int advanced, int channels, double level_db,
+                                        int max_sessions, const peaq_settings* settings, int fir_mode, peaq_broker** out) {
+  if (!devices || !out) return fail(PEAQ_ERR_ARG, "peaq_broker_create_multi: NULL argument");
+  *out = nullptr;
+  if (n_devices < 1 || n_devices > 64) return fail(PEAQ_ERR_ARG, "peaq_broker_create_multi: 1..64 devices");
+  if (max_sessions < n_devices) return fail(PEAQ_ERR_ARG, "peaq_broker_create_multi: fewer sessions than devices");
+  peaq_broker* b = new (std::nothrow) peaq_broker;
+  if (!b) return fail(PEAQ_ERR_NOMEM, "out of host memory");
+  b->advanced = advanced ? 1 : 0;
+  b->channels = channels;
+  b->level_db = level_db;
+  const int per_shard = (max_sessions + n_devices - 1) / n_devices;
+  b->max_sessions = per_shard * n_devices;
+  for (int i = 0; i < n_devices; ++i) {
+    peaq_ctx* c = nullptr;
+    int rc = peaq_ctx_create(devices[i], &c);
+    if (rc == PEAQ_OK && settings) rc = peaq_ctx_set_settings(c, settings);
+    if (rc == PEAQ_OK && fir_mode >= 0) rc = peaq_ctx_set_fir_mode(c, fir_mode);
+    peaq_broker* sh = nullptr;
+    if (rc == PEAQ_OK) rc = peaq_broker_create(c, advanced, channels, level_db, per_shard, &sh);
+    if (rc != PEAQ_OK) {
+      const std::string msg = g_err;
+      if (c) peaq_ctx_destroy(c);
+      peaq_broker_destroy(b);
+      return fail(rc, "peaq_broker_create_multi: device " + std::to_string(devices[i]) + ": " + msg);
+    }
+    b->shards.push_back(sh);
+    b->shard_ctx.push_back(c);
+    b->shard_open.push_back(0);
+  }
+  *out = b;
+  return PEAQ_OK;
+}
+
+extern "C" int peaq_broker_devices(const peaq_broker* b) { return !b ? 0 : broker_is_multi(b) ? (int)b->shards.size() : 1; }
+extern "C" size_t peaq_broker_stats_size(void) { return sizeof(peaq_broker_stats_t); }
+
 extern "C" int peaq_broker_stop(peaq_broker* b) {
   if (!b) return fail(PEAQ_ERR_ARG, "peaq_broker_stop: broker is NULL");
+  if (broker_is_multi(b)) {
+    int rc = PEAQ_OK;
+    for (peaq_broker* sh : b->shards) {
+      const int r = peaq_broker_stop(sh);
+      if (r != PEAQ_OK) rc = r;
+    }
+    return rc;
+  }
   if (b->running.exchange(false) && b->worker.joinable()) b->worker.join();
   b->tick_cv.notify_all();          // blocked pushers go on ticking inline
   return PEAQ_OK;
@@ -1839,6 +1898,12 @@ extern "C" int peaq_broker_stop(peaq_broker* b) {
 
 extern "C" void peaq_broker_destroy(peaq_broker* b) {
   if (!b) return;
+  if (broker_is_multi(b) || !b->ctx) {               // (no context: a multi broker whose creation failed half way)
+    for (peaq_broker* sh : b->shards) peaq_broker_destroy(sh);
+    for (peaq_ctx* c : b->shard_ctx) peaq_ctx_destroy(c);
+    delete b;
+    return;
+  }
   (void)peaq_broker_stop(b);
   (void)hipSetDevice(b->ctx->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
@@ -1864,6 +1929,22 @@ extern "C" void peaq_broker_destroy(peaq_broker* b) {
 
 extern "C" int peaq_broker_open(peaq_broker* b, int* session_id) {
   if (!b || !session_id) return fail(PEAQ_ERR_ARG, "peaq_broker_open: NULL argument");
+  if (broker_is_multi(b)) {                            // the device with the fewest open sessions takes it
+    std::lock_guard<std::mutex> place(b->tick_mu);
+    const int n = (int)b->shards.size();
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return b->shard_open[x] < b->shard_open[y]; });
+    for (int i : order) {
+      int local = -1;
+      if (peaq_broker_open(b->shards[i], &local) == PEAQ_OK) {
+        ++b->shard_open[i];
+        *session_id = i + n * local;
+        return PEAQ_OK;
+      }
+    }
+    return fail(PEAQ_ERR_STATE, "peaq_broker_open: all session slots are in use");
+  }
   std::lock_guard<std::mutex> tick(b->tick_mu);
   for (int sid = 0; sid < b->max_sessions; ++sid) {
     BrokerSlot& sl = *b->slots[sid];
@@ -1893,6 +1974,17 @@ static BrokerSlot* broker_slot(peaq_broker* b, int sid) {
 }
 
 extern "C" int peaq_broker_close(peaq_broker* b, int session_id) {
+  if (broker_is_multi(b)) {
+    int local;
+    peaq_broker* sh = broker_shard_of(b, session_id, &local);
+    if (!sh) return fail(PEAQ_ERR_ARG, "peaq_broker_close: bad session id");
+    const int rc = peaq_broker_close(sh, local);
+    if (rc == PEAQ_OK) {
+      std::lock_guard<std::mutex> place(b->tick_mu);
+      --b->shard_open[session_id % (int)b->shards.size()];
+    }
+    return rc;
+  }
   BrokerSlot* sl = broker_slot(b, session_id);
   if (!sl) return fail(PEAQ_ERR_ARG, "peaq_broker_close: bad broker or session id");
   std::lock_guard<std::mutex> tick(b->tick_mu);
@@ -1906,6 +1998,11 @@ extern "C" int peaq_broker_close(peaq_broker* b, int session_id) {
 
 // pad_chain (gstpeaq.c:613-640): only queues; the device work happens on the next tick
 extern "C" int peaq_broker_push(peaq_broker* b, int session_id, int pad, const float* data, size_t n) {
+  if (broker_is_multi(b)) {
+    int local;
+    peaq_broker* sh = broker_shard_of(b, session_id, &local);
+    return sh ? peaq_broker_push(sh, local, pad, data, n) : fail(PEAQ_ERR_ARG, "peaq_broker_push: bad session id");
+  }
   BrokerSlot* sl = broker_slot(b, session_id);
   if (!sl) return fail(PEAQ_ERR_ARG, "peaq_broker_push: bad broker or session id");
   if (pad != 0 && pad != 1) return fail(PEAQ_ERR_ARG, "peaq_broker_push: pad must be 0 (ref) or 1 (test)");
@@ -1951,6 +2048,11 @@ extern "C" int peaq_broker_push(peaq_broker* b, int session_id, int pad, const f
 }
 
 extern "C" int peaq_broker_flush(peaq_broker* b, int session_id) {
+  if (broker_is_multi(b)) {
+    int local;
+    peaq_broker* sh = broker_shard_of(b, session_id, &local);
+    return sh ? peaq_broker_flush(sh, local) : fail(PEAQ_ERR_ARG, "peaq_broker_flush: bad session id");
+  }
   BrokerSlot* sl = broker_slot(b, session_id);
   if (!sl) return fail(PEAQ_ERR_ARG, "peaq_broker_flush: bad broker or session id");
   if (b->failed.load()) return broker_failed(b, "peaq_broker_flush");
@@ -1964,6 +2066,17 @@ extern "C" int peaq_broker_flush(peaq_broker* b, int session_id) {
 
 extern "C" int peaq_broker_tick(peaq_broker* b, unsigned* n_active) {
   if (!b) return fail(PEAQ_ERR_ARG, "peaq_broker_tick: broker is NULL");
+  if (broker_is_multi(b)) {                            // every device's launch of this tick (they run side by side)
+    unsigned total = 0;
+    for (peaq_broker* sh : b->shards) {
+      unsigned n = 0;
+      const int rc = peaq_broker_tick(sh, &n);
+      if (rc != PEAQ_OK) return rc;
+      total += n;
+    }
+    if (n_active) *n_active = total;
+    return PEAQ_OK;
+  }
   std::lock_guard<std::mutex> tick(b->tick_mu);
   return broker_tick_checked(b, n_active);
 }
@@ -1981,6 +2094,11 @@ static bool broker_slot_busy(const peaq_broker* b, BrokerSlot* sl) {
 }
 
 extern "C" int peaq_broker_results(peaq_broker* b, int session_id, peaq_result* out) {
+  if (broker_is_multi(b)) {
+    int local;
+    peaq_broker* sh = broker_shard_of(b, session_id, &local);
+    return sh ? peaq_broker_results(sh, local, out) : fail(PEAQ_ERR_ARG, "peaq_broker_results: bad session id");
+  }
   BrokerSlot* sl = broker_slot(b, session_id);
   if (!sl || !out) return fail(PEAQ_ERR_ARG, "peaq_broker_results: bad broker, session id or out");
   std::lock_guard<std::mutex> tick(b->tick_mu);
@@ -2003,6 +2121,16 @@ extern "C" int peaq_broker_results(peaq_broker* b, int session_id, peaq_result* 
 
 extern "C" int peaq_broker_start(peaq_broker* b, unsigned period_us) {
   if (!b) return fail(PEAQ_ERR_ARG, "peaq_broker_start: broker is NULL");
+  if (broker_is_multi(b)) {                            // one tick thread per device
+    for (peaq_broker* sh : b->shards) {
+      const int rc = peaq_broker_start(sh, period_us);
+      if (rc != PEAQ_OK) {
+        (void)peaq_broker_stop(b);
+        return rc;
+      }
+    }
+    return PEAQ_OK;
+  }
   if (b->running.exchange(true)) return fail(PEAQ_ERR_STATE, "peaq_broker_start: already running");
   b->period_us = period_us ? period_us : 2000;
   b->worker = std::thread([b]() {
@@ -2027,6 +2155,39 @@ extern "C" int peaq_broker_start(peaq_broker* b, unsigned period_us) {
 
 extern "C" int peaq_broker_stats(peaq_broker* b, peaq_broker_stats_t* out) {
   if (!b || !out) return fail(PEAQ_ERR_ARG, "peaq_broker_stats: NULL argument");
+  if (broker_is_multi(b)) {
+    // counts add up over the devices (max_active: the most sessions the node served in one tick period, each
+    // device's own maximum); times: the worst device's maximum and 99th percentile, means weighted by their samples
+    peaq_broker_stats_t acc{};
+    double host_w = 0., dev_w = 0.;
+    for (peaq_broker* sh : b->shards) {
+      peaq_broker_stats_t s{};
+      const int rc = peaq_broker_stats(sh, &s);
+      if (rc != PEAQ_OK) return rc;
+      acc.ticks += s.ticks;
+      acc.launches += s.launches;
+      acc.frames += s.frames;
+      acc.max_active += s.max_active;
+      acc.worker_failed |= s.worker_failed;
+      acc.tick_host_us_max = std::max(acc.tick_host_us_max, s.tick_host_us_max);
+      acc.tick_host_us_p99 = std::max(acc.tick_host_us_p99, s.tick_host_us_p99);
+      acc.tick_device_us_max = std::max(acc.tick_device_us_max, s.tick_device_us_max);
+      acc.tick_device_us_p99 = std::max(acc.tick_device_us_p99, s.tick_device_us_p99);
+      acc.latency_us_max = std::max(acc.latency_us_max, s.latency_us_max);
+      acc.latency_us_p99 = std::max(acc.latency_us_p99, s.latency_us_p99);
+      acc.tick_host_us_mean += s.tick_host_us_mean * (double)s.launches;
+      acc.tick_device_us_mean += s.tick_device_us_mean * (double)s.launches;
+      host_w += (double)s.launches;
+      dev_w += (double)s.launches;
+      acc.latency_us_mean += s.latency_us_mean * (double)s.latency_samples;
+      acc.latency_samples += s.latency_samples;
+    }
+    if (host_w > 0.) acc.tick_host_us_mean /= host_w;
+    if (dev_w > 0.) acc.tick_device_us_mean /= dev_w;
+    if (acc.latency_samples) acc.latency_us_mean /= (double)acc.latency_samples;
+    *out = acc;
+    return PEAQ_OK;
+  }
   std::lock_guard<std::mutex> tick(b->tick_mu);
   out->ticks = b->n_ticks;
   out->launches = b->n_launches;

@@ -99,7 +99,8 @@ shared_context (void)
 /* PEAQ_AMD_BROKER=<max sessions>: a process that hosts many `peaq` elements lets ONE broker run
  * the frames of all of them as one batched launch per tick (include/peaq_amd.h, "broker").  One
  * broker per (version, channel count) at the default playback level; an element with another
- * level keeps its own session. */
+ * level keeps its own session.  PEAQ_AMD_DEVICES=0,1,...: the broker spans those GPUs
+ * (peaq_broker_create_multi: one device broker each, elements dealt out to the least loaded). */
 static peaq_broker *
 shared_broker (gboolean advanced, gint channels)
 {
@@ -114,7 +115,21 @@ shared_broker (gboolean advanced, gint channels)
   if (!brokers[adv][channels]) {
     peaq_ctx *ctx = shared_context ();
     const gchar *period = g_getenv ("PEAQ_AMD_BROKER_PERIOD_US");
-    if (ctx && peaq_broker_create (ctx, adv, channels, 92., atoi (max), &brokers[adv][channels]) == PEAQ_OK) {
+    const gchar *devs = g_getenv ("PEAQ_AMD_DEVICES");
+    gint devices[64], n_devices = 0, rc;
+    if (devs) {
+      gchar **tok = g_strsplit (devs, ",", 64);
+      for (gint i = 0; tok[i] && n_devices < 64; i++)
+        if (*tok[i])
+          devices[n_devices++] = atoi (tok[i]);
+      g_strfreev (tok);
+    }
+    if (n_devices > 0)
+      rc = ctx ? peaq_broker_create_multi (devices, n_devices, adv, channels, 92., MAX (atoi (max), n_devices), NULL,
+                                           peaq_ctx_get_fir_mode (ctx), &brokers[adv][channels]) : PEAQ_ERR_DEVICE;
+    else
+      rc = ctx ? peaq_broker_create (ctx, adv, channels, 92., atoi (max), &brokers[adv][channels]) : PEAQ_ERR_DEVICE;
+    if (rc == PEAQ_OK) {
       if (peaq_broker_start (brokers[adv][channels], period ? (unsigned) atoi (period) : 0) != PEAQ_OK)
         GST_WARNING ("libpeaq_amd: %s", peaq_last_error ());
     } else {

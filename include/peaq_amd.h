@@ -182,6 +182,17 @@ typedef struct peaq_broker_stats_t {
 } peaq_broker_stats_t;
 int  peaq_broker_create  (peaq_ctx *ctx, int advanced, int channels, double playback_level_db,
                           int max_sessions, peaq_broker **out);
+/* The same over SEVERAL GPUs of a node (BASELINE.json configs[4] on an 8-GPU box): one device broker -- its own
+ * context, slots, launch stream and tick thread -- per entry of `devices` (an ordinal may appear more than once:
+ * two brokers on that GPU); a session is opened on the device that holds the fewest, stays there, and every call
+ * below is forwarded by its id.  Sessions never exchange anything (gstpeaq.c:110-139: all state is per element), so
+ * the devices' ticks are independent.  `settings` NULL = the reference's shipped values, `fir_mode` < 0 = the
+ * engine's default (PEAQ_FIR_*).  max_sessions is rounded up to a multiple of the device count.  peaq_broker_stats
+ * adds the counts up over the devices and reports the worst device's times. */
+int  peaq_broker_create_multi (const int *devices, int n_devices, int advanced, int channels,
+                               double playback_level_db, int max_sessions, const peaq_settings *settings,
+                               int fir_mode, peaq_broker **out);
+int  peaq_broker_devices (const peaq_broker *b);                       /* 1 for peaq_broker_create's */
 void peaq_broker_destroy (peaq_broker *b);
 int  peaq_broker_open    (peaq_broker *b, int *session_id);            /* gst_peaq_init / READY->PAUSED      */
 int  peaq_broker_close   (peaq_broker *b, int session_id);             /* finalize                           */
@@ -192,6 +203,8 @@ int  peaq_broker_results (peaq_broker *b, int session_id, peaq_result *out);  /*
 int  peaq_broker_start   (peaq_broker *b, unsigned period_us);         /* own tick thread (0 = 2000 us)      */
 int  peaq_broker_stop    (peaq_broker *b);
 int  peaq_broker_stats   (peaq_broker *b, peaq_broker_stats_t *out);
+size_t peaq_broker_stats_size (void);   /* sizeof (peaq_broker_stats_t) in THIS library: a caller built against another
+                                         * header compares before it hands over a buffer */
 
 /* ---- batch API ------------------------------------------------------------
  * n_pairs whole pairs, inputs already in device memory as interleaved F32
@@ -278,6 +291,13 @@ int peaq_debug_filterbank (peaq_ctx *ctx, int channels, double playback_level_db
 #define PEAQ_DEBUG_BACKEND_DOUBLES 912
 int peaq_debug_backend (peaq_ctx *ctx, int channels, int n_frames, const double *host_records,
                         double *host_out, peaq_result *result);
+
+/* Host only, no device: self-check of the constant tables of the FP64 filter-bank engine.  Its long filters run
+ * in a "block-sum" form (three rectangular windows per Hann window, running sums over 32-sample blocks: DESIGN.md 3);
+ * the function evaluates that form and the direct tile of the short filters FROM THE TABLES on a pseudo-random
+ * window and returns the largest deviation from the plain sums of fbearmodel.c:399-435, relative to each band's
+ * largest output (about 4e-15).  tests/test_capi_host.py runs it on the CPU. */
+double peaq_debug_fb_tables_selfcheck (void);
 
 #ifdef __cplusplus
 }

@@ -97,3 +97,28 @@ def test_settings_default_are_the_reference_s_shipped_values():
     if not torch.cuda.is_available():
         h = C.c_void_p()
         assert L.peaq_ctx_create(0, C.byref(h)) != 0 and b"HIP device" in L.peaq_last_error()
+
+
+def test_fp64_filter_bank_tables_reproduce_the_plain_sums(lib):
+    """The FP64 engine evaluates its 24 long filters as running block sums (three rectangular windows per Hann
+    window, own coefficients on the two edge blocks) and the 16 short ones as one folded tile: both forms,
+    evaluated on the host from the very tables the kernel reads, against the sums of fbearmodel.c:399-435."""
+    lib.peaq_debug_fb_tables_selfcheck.restype = C.c_double
+    lib.peaq_debug_fb_tables_selfcheck.argtypes = []
+    worst = lib.peaq_debug_fb_tables_selfcheck()
+    assert 0. < worst < 5e-14, worst
+
+
+def test_multi_device_broker_argument_checks(lib):
+    h = C.c_void_p()
+    devs = (C.c_int * 2)(0, 0)
+    assert lib.peaq_broker_create_multi(None, 2, 0, 2, C.c_double(92.), 8, None, -1, C.byref(h)) == -1
+    assert lib.peaq_broker_create_multi(devs, 0, 0, 2, C.c_double(92.), 8, None, -1, C.byref(h)) == -1
+    assert lib.peaq_broker_create_multi(devs, 2, 0, 2, C.c_double(92.), 1, None, -1, C.byref(h)) == -1
+    import torch
+    if not torch.cuda.is_available():                  # no device: creation fails with the device's message, nothing leaks
+        rc = lib.peaq_broker_create_multi(devs, 2, 0, 2, C.c_double(92.), 8, None, -1, C.byref(h))
+        assert rc != 0 and not h and b"device 0" in lib.peaq_last_error()
+    lib.peaq_broker_stats_size.restype = C.c_size_t
+    from gstpeaq_amd.capi import _BrokerStats
+    assert lib.peaq_broker_stats_size() == C.sizeof(_BrokerStats)

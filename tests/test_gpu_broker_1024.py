@@ -91,3 +91,17 @@ def test_one_gst_process_hosts_1024_elements_on_the_broker():
     assert out.returncode == 0, out.stderr[-2000:]
     odgs = re.findall(r"Objective Difference Grade: (-?[0-9.]+|-?nan)", out.stdout)
     assert sorted(odgs) == sorted(["0.171"] * (n // 2) + ["-2.007"] * (n // 2)), (len(odgs), sorted(set(odgs)))
+
+
+@pytest.mark.parametrize("advanced", [False, True], ids=["basic", "advanced"])
+def test_1024_live_sessions_over_two_device_brokers(advanced):
+    """peaq_broker_create_multi (configs[4] on a node with several GPUs): the sessions are dealt out to one
+    device broker per entry of `devices` -- here {0, 0}: two contexts, two sets of slots, two tick threads on the one
+    GPU of the box -- and every session's result still equals the batch path's."""
+    args = ["--sessions", 1024, "--seconds", 1.0, "--threads", 16, "--devices", "0,0"] + (["--advanced"] if advanced else [])
+    d = run_feeder(*args)
+    assert d["devices"] == 2 and d["sessions_per_device_min"] == d["sessions_per_device_max"] == 512
+    assert d["mismatches"] == 0 and d["feed_errors"] == 0 and d["worker_failed"] == 0
+    assert d["max_abs_dodg_vs_batch"] == 0.0 if not advanced else d["max_abs_dodg_vs_batch"] < 1e-6
+    assert d["max_active"] >= 512, d                     # the sum of both devices' largest launches
+    assert d["frame_pairs"] == 1024 * 46                 # 1 s: 45 full frames + the flush frame

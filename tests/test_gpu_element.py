@@ -129,6 +129,12 @@ def test_many_elements_share_the_broker():
     assert out.returncode == 0, out.stderr[-2000:]
     odgs = [l.split()[3] for l in out.stdout.splitlines() if l.startswith("Objective Difference Grade:")]
     assert odgs == ["-3.612"] * 4, out.stdout[-1500:]
+    # PEAQ_AMD_DEVICES: the shared broker spans several GPUs (here two device brokers on the one GPU of the box)
+    env["PEAQ_AMD_DEVICES"] = "0,0"
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    odgs = sorted(l.split()[3] for l in out.stdout.splitlines() if l.startswith("Objective Difference Grade:"))
+    assert odgs == sorted(["0.171"] * (n // 2) + ["-2.007"] * (n // 2)), out.stdout[-1500:]
 
 
 def test_element_playback_level_property():

@@ -14,7 +14,10 @@
 //
 //   broker_feeder [--sessions N] [--seconds S] [--threads T] [--chunk SAMPLES]
 //                 [--channels C] [--advanced] [--period-us P] [--seed0 K] [--ragged]
-//                 [--realtime]
+//                 [--realtime] [--devices 0,0,1,...]
+// --devices: peaq_broker_create_multi on the listed GPU ordinals (an ordinal may repeat: two device brokers on one
+//   GPU) instead of one broker on device 0; the JSON line then carries "devices" and every session's id says which
+//   device broker serves it (id % devices).
 // --realtime: every session delivers --chunk samples per pad every chunk / 48000 s (1024: one
 // frame-pair per 21.3 ms, the pace of a live pipeline) instead of as fast as the feeders can
 // push; the latency figures of peaq_broker_stats_t are what this mode is for.
@@ -23,6 +26,7 @@
 // Build: make -C tools   (hipcc; links ../gstpeaq_amd/libpeaq_amd.so)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -64,6 +68,7 @@ int main(int argc, char** argv) {
   int sessions = 1024, threads = 16, channels = 2, advanced = 0, ragged = 0, realtime = 0;
   double seconds = 2.0;
   unsigned chunk = 4096, period_us = 1000, seed0 = 1;
+  std::vector<int> devices;
   for (int i = 1; i < argc; ++i) {
     auto arg = [&](const char* name) { return !std::strcmp(argv[i], name) && i + 1 < argc; };
     if (arg("--sessions")) sessions = std::atoi(argv[++i]);
@@ -73,6 +78,12 @@ int main(int argc, char** argv) {
     else if (arg("--channels")) channels = std::atoi(argv[++i]);
     else if (arg("--period-us")) period_us = (unsigned)std::atoi(argv[++i]);
     else if (arg("--seed0")) seed0 = (unsigned)std::strtoul(argv[++i], nullptr, 0);
+    else if (arg("--devices")) {
+      for (const char* p = argv[++i]; *p;) {
+        devices.push_back((int)std::strtol(p, const_cast<char**>(&p), 10));
+        if (*p == ',') ++p;
+      }
+    }
     else if (!std::strcmp(argv[i], "--advanced")) advanced = 1;
     else if (!std::strcmp(argv[i], "--ragged")) ragged = 1;
     else if (!std::strcmp(argv[i], "--realtime")) realtime = 1;
@@ -109,9 +120,22 @@ int main(int argc, char** argv) {
 
   // ---- the live sessions ---------------------------------------------------------------------------
   peaq_broker* br = nullptr;
-  CHECK_PEAQ(peaq_broker_create(ctx, advanced, channels, 92., sessions, &br));
+  if (devices.empty())
+    CHECK_PEAQ(peaq_broker_create(ctx, advanced, channels, 92., sessions, &br));
+  else
+    CHECK_PEAQ(peaq_broker_create_multi(devices.data(), (int)devices.size(), advanced, channels, 92., sessions, nullptr,
+                                        peaq_ctx_get_fir_mode(ctx), &br));
   std::vector<int> sid(sessions);
   for (int s = 0; s < sessions; ++s) CHECK_PEAQ(peaq_broker_open(br, &sid[s]));
+  // how the sessions were dealt out
+  const int n_dev = peaq_broker_devices(br);
+  std::vector<int> per_dev(n_dev, 0);
+  for (int s = 0; s < sessions; ++s) ++per_dev[sid[s] % n_dev];
+  int dev_min = sessions, dev_max = 0;
+  for (int d = 0; d < n_dev; ++d) {
+    dev_min = std::min(dev_min, per_dev[d]);
+    dev_max = std::max(dev_max, per_dev[d]);
+  }
   CHECK_PEAQ(peaq_broker_start(br, period_us));
 
   std::atomic<int> feed_errors{0};
@@ -190,8 +214,9 @@ int main(int argc, char** argv) {
   peaq_broker_destroy(br);
   peaq_ctx_destroy(ctx);
 
+  std::printf("{\"devices\": %d, \"sessions_per_device_min\": %d, \"sessions_per_device_max\": %d, ", n_dev, dev_min, dev_max);
   std::printf(
-      "{\"sessions\": %d, \"advanced\": %d, \"channels\": %d, \"seconds_per_session\": %g, \"feeder_threads\": %d, "
+      "\"sessions\": %d, \"advanced\": %d, \"channels\": %d, \"seconds_per_session\": %g, \"feeder_threads\": %d, "
       "\"chunk\": %u, \"ragged\": %d, \"period_us\": %u, \"frame_pairs\": %.0f, \"feed_s\": %.4f, \"total_s\": %.4f, "
       "\"frame_pairs_per_s\": %.1f, \"x_realtime\": %.1f, \"ticks\": %llu, \"launches\": %llu, "
       "\"max_active\": %u, \"worker_failed\": %u, \"feed_errors\": %d, \"mismatches\": %d, \"odg_nan\": %d, "

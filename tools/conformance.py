@@ -9,7 +9,11 @@ reference implementation reaches ("Actual DI" of doc/conformance_*_table.xml; eq
 decimals is the pass criterion of checkconformanceresults.sh:24-31) and the ITU values, then the
 bias / mean square error against ITU (make_conformance_tables.sh:78-81).
 
-  CONFORMANCEDATADIR=/path/to/items python tools/conformance.py [--cli] [--mode basic|advanced|both]
+  CONFORMANCEDATADIR=/path/to/items python tools/conformance.py [--cli] [--mode basic|advanced|both] [--gpus N]
+
+--gpus N deals a version's items out to N GPUs (a contiguous block of items per device, gstpeaq_amd.parallel.shard:
+pairs are closed computations, nothing is exchanged) and runs the devices' launches from N threads; --devices
+0,0 names the ordinals explicitly (an ordinal may repeat).
 
 Exit status like the reference script: 77 when the data are absent (test NOT run), 1 on a
 mismatch, 0 when every item matches.  --cli runs the `peaq` command-line tool per item instead of
@@ -36,9 +40,12 @@ def item_files(datadir, item):
 
 
 def run_batch(ctx, pairs, advanced):
-    """pairs: list of (ref, test) float32 [n, ch]; one batched launch -> list of result dicts"""
+    """pairs: list of (ref, test) float32 [n, ch]; one batched launch on ctx's device -> list of result dicts"""
     import torch
     import gstpeaq_amd
+    if not pairs:
+        return []
+    dev = torch.device("cuda", int(ctx.device))
     ch = pairs[0][0].shape[1]
     stride = max(max(len(r), len(t)) for r, t in pairs)
     stride += stride & 1
@@ -49,8 +56,20 @@ def run_batch(ctx, pairs, advanced):
     for i, (r, t) in enumerate(pairs):
         ref[i, :len(r)], test[i, :len(t)] = r, t
         n_ref[i], n_test[i] = len(r), len(t)
-    return gstpeaq_amd.batch_run(ctx, advanced, torch.from_numpy(ref).cuda(), torch.from_numpy(test).cuda(),
+    return gstpeaq_amd.batch_run(ctx, advanced, torch.from_numpy(ref).to(dev), torch.from_numpy(test).to(dev),
                                  n_ref, n_test)
+
+
+def run_sharded(ctxs, pairs, advanced):
+    """the pairs dealt out to the contexts' devices (contiguous blocks), one launch per device, side by side"""
+    from concurrent.futures import ThreadPoolExecutor
+    from gstpeaq_amd import parallel
+    if len(ctxs) == 1:
+        return run_batch(ctxs[0], pairs, advanced)
+    blocks = [parallel.shard(len(pairs), r, len(ctxs)) for r in range(len(ctxs))]
+    with ThreadPoolExecutor(len(ctxs)) as pool:
+        parts = list(pool.map(lambda a: run_batch(a[0], pairs[a[1][0]:a[1][1]], advanced), zip(ctxs, blocks)))
+    return [res for part in parts for res in part]
 
 
 def run_cli(ref, cod, advanced):
@@ -64,7 +83,7 @@ def run_cli(ref, cod, advanced):
     return dict(di=di, odg=odg)
 
 
-def check(mode, items, datadir, use_cli, ctx):
+def check(mode, items, datadir, use_cli, ctxs):
     advanced = mode == "advanced"
     print(f"{mode.capitalize()} version:")
     if use_cli:
@@ -81,7 +100,7 @@ def check(mode, items, datadir, use_cli, ctx):
             by_ch.setdefault(r.shape[1], []).append((idx, r, t))
         results = [None] * len(items)
         for ch, group in by_ch.items():                      # one launch per channel layout
-            for (idx, _, _), res in zip(group, run_batch(ctx, [(r, t) for _, r, t in group], advanced)):
+            for (idx, _, _), res in zip(group, run_sharded(ctxs, [(r, t) for _, r, t in group], advanced)):
                 results[idx] = res
     ok = True
     d_odg, d_di = [], []
@@ -105,6 +124,8 @@ def main():
     ap.add_argument("--mode", choices=["basic", "advanced", "both"], default="both")
     ap.add_argument("--cli", action="store_true")
     ap.add_argument("--datadir", default=os.environ.get("CONFORMANCEDATADIR"))
+    ap.add_argument("--gpus", type=int, default=1, help="deal the items out to this many GPUs (ordinals 0..N-1)")
+    ap.add_argument("--devices", default=None, help="explicit device ordinals, e.g. 0,1,2,3 (overrides --gpus)")
     args = ap.parse_args()
     if not args.datadir:
         print("CONFORMANCEDATADIR not set, conformance test NOT run.")
@@ -119,13 +140,14 @@ def main():
         print(f"Reference data incomplete ({len(set(missing))} files missing, e.g. {missing[0]}), "
               "conformance test NOT run.")
         return 77
-    ctx = None
+    ctxs = None
     if not args.cli:
         import gstpeaq_amd
-        ctx = gstpeaq_amd.Context(0)
+        devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(max(args.gpus, 1)))
+        ctxs = [gstpeaq_amd.Context(d) for d in devices]
     ok = True
     for m in modes:
-        ok &= check(m, tables[m], args.datadir, args.cli, ctx)
+        ok &= check(m, tables[m], args.datadir, args.cli, ctxs)
     return 0 if ok else 1
 
 
