@@ -279,9 +279,9 @@ struct FbSignalState {
   double e0_hist[kFbBands][kFbTaps];
   double excitation[kFbBands];
   double ring[kFbRing];         // the last 1456 filtered samples, newest first
-  // Largest |filtered sample| of a launch, for the split-FP16 operands' scale (peaq_fb.hip): slot launch_idx % 3
-  // holds { this launch, the signal's previous launch } -- three slots because the high-pass walk of launch
-  // i + 1 runs beside the bank kernel of launch i -- and peak_last what the next walk will call "previous".
+  // Largest |filtered sample| for the split-FP16 operands' scale (peaq_fb.hip): slot launch_idx % 3 holds
+  // { this launch's blocks, the window's head = the 1456 filtered samples in front of them } -- three slots because
+  // the high-pass walk of launch i + 1 runs beside the bank kernel of launch i; peak_last = the last launch's own peak.
   double peak_slot[3][2];
   double peak_last;
   // FP64 engine, block-sum form of the long filters (kBs*): per band and exponential the last J = bs_whole[band]

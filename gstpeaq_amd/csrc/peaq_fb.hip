@@ -91,14 +91,21 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) nb_max = max(nb_max, (unsigned)__shfl_xor((int)nb_max, d, 64));
 
-  // history: the newest 1456 filtered samples of the previous launch sit at the row's tail
+  // history: the newest 1456 filtered samples of the previous launch sit at the row's tail.  Their peak is taken
+  // here, where it is exact: with launches of a block or two (sessions, the broker) the head spans up to eight
+  // earlier launches, and "this launch and the previous one" would miss a burst that lies further back
+  double peak_head = 0.;
   if (nb_mine > 0) {
     if (first) {
       for (int i = 0; i < kFbRing; ++i) my_row[i] = 0.;
     } else {
       const size_t tail = (size_t)prev_blocks * kFbFrame;
       const double* __restrict__ prev_row = a.hp_prev ? a.hp_prev + (size_t)state_idx * row_len : my_row;
-      for (int i = 0; i < kFbRing; ++i) my_row[i] = prev_row[tail + i];
+      for (int i = 0; i < kFbRing; ++i) {
+        const double v = prev_row[tail + i];
+        my_row[i] = v;
+        peak_head = fmax(peak_head, fabs(v));
+      }
     }
   }
   HpWalk w{st->hp[0], st->hp[1], st->hp[2], st->hp[3], st->hp[4], st->hp[5]};
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
     st->hp[5] = fin.y2b;
     const int slot = a.launch_idx % 3;
     st->peak_slot[slot][0] = peak_fin;
-    st->peak_slot[slot][1] = first ? 0. : st->peak_last;   // the window's head is the previous launch's tail
+    st->peak_slot[slot][1] = peak_head;                // the window's head: the last 1456 filtered samples before this launch
     st->peak_last = peak_fin;
   }
 }

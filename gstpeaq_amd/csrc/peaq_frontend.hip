@@ -922,7 +922,11 @@ void frontend_kernel(FrontendArgs a) {
     double cavg = 0.;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      c[m] *= rsqrt_pos(d0 * (d0 + dk[m]));          // NaN when d0 = 0 (identical signals), as in the reference
+      // NaN when d0 = 0 (identical signals), as in the reference.  (d0 + dk: the reference runs dk = d0;
+      // dk += d[i+256]^2 - d[i]^2 (movs.c:1413-1418) -- here the increments are summed first, as a prefix over the
+      // lanes, and d0 is added last: the same sum in another order, last-bit differences where d0 dwarfs the
+      // increments; DESIGN.md 4, "not bit-exact by design")
+      c[m] *= rsqrt_pos(d0 * (d0 + dk[m]));
       cavg += c[m];
     }
     // the mean is removed before the window (the shipped EHS_SUBTRACT_DC_BEFORE_WINDOW, movs.c:1409-1421) or

@@ -322,7 +322,9 @@ __device__ __forceinline__ double log_tab(double x, const double* __restrict__ t
   int e = __builtin_amdgcn_frexp_exp(x);
   // fraction bits 51..45 of m, rounded to nearest: the carry of an all-ones fraction lands in the exponent's
   // lowest bit, which is 0 for [0.5, 1) -- so bits 20..13 of the high word read 0..128
-  const unsigned idx = __builtin_amdgcn_ubfe((unsigned)__double2hiint(m) + 0x1000u, 13, 8);
+  // (0 .. 128 for every finite positive argument; a NaN's mantissa field can say up to 255: clamped, so that the
+  // read stays inside the 130-entry table whatever comes in -- the result is NaN either way)
+  const unsigned idx = min(__builtin_amdgcn_ubfe((unsigned)__double2hiint(m) + 0x1000u, 13, 8), 128u);
   const double2 t = *reinterpret_cast<const double2*>(tab + 2 * idx);
   e -= idx < (unsigned)kLogTabFold ? 1 : 0;
   const double r = fma(m, t.x, -1.);

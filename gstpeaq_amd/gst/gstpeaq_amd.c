@@ -90,6 +90,9 @@ shared_context (void)
       if (!(max && atoi (max) > 0) && !g_getenv ("PEAQ_AMD_FIR") && !g_getenv ("PEAQ_AMD_FIR_FP64")
           && peaq_ctx_set_fir_mode (ctx, PEAQ_FIR_F64) != PEAQ_OK)
         GST_WARNING ("libpeaq_amd: %s", peaq_last_error ());
+      /* decided once per process, when the first element is created: say which it was */
+      GST_INFO ("libpeaq_amd: device %d, filter-bank arithmetic of the advanced version: %s", peaq_ctx_device (ctx),
+                peaq_ctx_get_fir_mode (ctx) == PEAQ_FIR_F64 ? "f64" : peaq_ctx_get_fir_mode (ctx) == PEAQ_FIR_F32 ? "f32" : "f16x3");
     }
     g_once_init_leave (&once, 1);
   }

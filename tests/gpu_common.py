@@ -19,7 +19,7 @@ GOLD = Path(__file__).resolve().parent / "golden"
 #   chunks  one stream cut into launches in different ways (session, broker, batch) against itself (relative)
 MODES = ("default", "f64")
 TOL = {"default": dict(movs=2e-6, odg=1e-6, blocks=1e-4, chunks=1e-9),
-       "f64": dict(movs=1e-7, odg=1e-6, blocks=1e-9, chunks=1e-10)}
+       "f64": dict(movs=1e-7, odg=1e-7, blocks=1e-9, chunks=1e-10)}
 _MODE = "default"
 _CTX = {}
 

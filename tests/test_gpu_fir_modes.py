@@ -130,4 +130,22 @@ def test_samples_far_beyond_full_scale_are_scaled_not_saturated():
         live = s.results()
         s.close()
         assert abs(live["odg"] - exp["odg"]) <= 1e-6
+    # ... also fed ONE filter-bank block (192 samples) at a time: the window's head then spans eight earlier
+    # launches, and the burst (+40 dB over full scale for a moment, 2..7 launches back) must still set the scale --
+    # the head's peak is taken from the head itself (fb_hp_kernel), not from "this launch and the one before"
+    hot_r, hot_t = ref.copy(), test.copy()
+    hot_r[20000:20150] = np.float32(100.) * np.sign(hot_r[20000:20150] + np.float32(1e-9))
+    hot_t[20000:20150] = hot_r[20000:20150]
+    r = torch.from_numpy(np.ascontiguousarray(hot_r[None])).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(hot_t[None])).cuda()
+    exp = gstpeaq_amd.batch_run(gpu_common.ctx("f64"), 1, r, t)[0]
+    s = gstpeaq_amd.Session(c, 1, 2)
+    for lo in range(0, len(hot_r), 192):
+        s.push_ref(hot_r[lo:lo + 192])
+        s.push_test(hot_t[lo:lo + 192])
+    s.flush()
+    live = s.results()
+    s.close()
+    assert np.isfinite(live["odg"]) and abs(live["odg"] - exp["odg"]) <= 1e-6, (live["odg"], exp["odg"])
+    np.testing.assert_allclose(live["movs"][:5], exp["movs"][:5], rtol=2e-6, atol=1e-9)
     c.close()

@@ -22,7 +22,7 @@ def _records(golden_dir, advanced):
 def _check(got, rec):
     exp = np.array([float(v) for v in rec["movs"]])
     adv = rec["case"]["advanced"]
-    odg_tol = gpu.tol("odg") if adv else 1e-7
+    odg_tol = gpu.tol("odg", advanced=adv)
     assert got["frames"] == rec["frames"]
     np.testing.assert_allclose(got["movs"][: len(exp)], exp, rtol=gpu.tol("movs", adv), atol=1e-9,
                                err_msg=f"{rec['variant']} {rec['case']['name']}")
@@ -45,7 +45,7 @@ def test_batch_matches_the_reference_built_with_other_settings(golden_dir, advan
             if rec["odg"] != rec["odg_default"]:
                 ctx.set_settings()
                 dflt = gpu.run_batch([case_defs.make_inputs(case)], advanced, case["channels"])[0]
-                assert abs(dflt["odg"] - rec["odg_default"]) <= (gpu.tol("odg") if advanced else 1e-7)
+                assert abs(dflt["odg"] - rec["odg_default"]) <= gpu.tol("odg", advanced=advanced)
     finally:
         ctx.set_settings()
 
