@@ -395,8 +395,23 @@ def main():
         tf = flops / fb_s / 1e12 if fb_s > 0 else 0.0
         mode = ctx.fir_mode()
         peak = {"f64": FP64_VECTOR_PEAK_TFLOPS, "f32": FP32_MATRIX_PEAK_TFLOPS, "f16x3": FP16_MATRIX_PEAK_TFLOPS}[mode]
+        extra = {}
+        if mode == "f64":
+            # The FP64 engine does not evaluate the reference's sums tap by tap any more ("block-sum
+            # form"): per sub-sample and signal its matrix instructions carry 24 bands x 8 rows x 32 multiply-adds
+            # (enter rows of the three rectangular windows + the block the window ends in) and one direct tile of
+            # 30 K steps x 4 delays x 16 bands x {re, im} for the 16 short filters.  `achieved` / `frac` stay what
+            # they were -- the REFERENCE's operation count over this kernel's time, comparable from round to round
+            # (it may pass 1: the kernel does less than it is credited with) -- and the kernel's own count stands
+            # beside them: the fraction of the matrix pipe's time its matrix instructions fill.
+            issued = blocks * args.channels * 2 * 6 * (24 * 8 * 32 + 30 * 4 * 16 * 2) * 2
+            extra = {"reference_flop_per_subsample": 10914 * 6, "matrix_flop_per_subsample": (24 * 8 * 32 + 30 * 4 * 16 * 2) * 2,
+                     "matrix_flop_per_launch": issued / max(timing["fb_launches"], 1),
+                     "matrix_pipe_frac": issued / fb_s / 1e12 / peak if fb_s > 0 else None,
+                     "algorithm": "block-sum form: bands 0..23 as running sums over 32-sample blocks (Hann window = three "
+                                  "rectangular windows), bands 24..39 direct; fbearmodel.c:399-435"}
         return {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
-                "frac": tf / peak, "traffic": None,
+                "frac": tf / peak, "traffic": None, **extra,
                 "kernel": {"f64": "fb_bank_kernel<MfmaF64>", "f32": "fb_bank_kernel<MfmaF32>", "f16x3": "fb_bank_kernel<MfmaH3>"}[mode],
                 "peak_is": {"f64": "FP64 matrix = vector peak", "f32": "FP32 matrix peak (f32-input MFMA), MI355X_MICROARCH.md",
                             "f16x3": "dense FP16 matrix peak, MI355X_MICROARCH.md; the kernel issues 6x the algorithmic "

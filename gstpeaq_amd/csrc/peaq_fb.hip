@@ -503,7 +503,7 @@ __device__ __forceinline__ void bs_tile(const double* __restrict__ win, const do
 
 // The running sums of one exponential over the wave's outputs: lane t gets r^(t+1) v + sum_{s <= t} r^(t - s) u_s
 // from (pr, pi) = r^(lane + 1) alone: every input is turned back into the frame of output -1 (times conj r^(s+1)),
-// the frame's plain prefix sum is taken (DPP row shifts, three row totals through the scalar registers) and
+// the frame's plain prefix sum is taken (DPP row shifts and row broadcasts) and
 // turned forward again.  |r| = 1: the turns cost no accuracy.
 __device__ __forceinline__ void bs_chain(double& re, double& im, double vr, double vi, double pr, double pi, int lane) {
   double ar = fma(pr, re, pi * im), ai = fma(pr, im, -pi * re);       // conj(p) u
@@ -515,13 +515,11 @@ __device__ __forceinline__ void bs_chain(double& re, double& im, double vr, doub
   PEAQ_BS_LEVEL(4)
   PEAQ_BS_LEVEL(8)
 #undef PEAQ_BS_LEVEL
-  // what came before a row: v and the totals of the rows in front of it
-  const double t0r = vr + read_lane<15>(ar), t0i = vi + read_lane<15>(ai);
-  const double t1r = t0r + read_lane<31>(ar), t1i = t0i + read_lane<31>(ai);
-  const double t2r = t1r + read_lane<47>(ar), t2i = t1i + read_lane<47>(ai);
-  const int row = lane >> 4;
-  ar += row == 0 ? vr : row == 1 ? t0r : row == 2 ? t1r : t2r;
-  ai += row == 0 ? vi : row == 1 ? t0i : row == 2 ? t1i : t2i;
+  // what came before a row: the rows in front of it (two DPP broadcasts, peaq_wave.h) and v
+  ar += row_carry_15(ar);
+  ai += row_carry_15(ai);
+  ar += row_carry_31(ar) + vr;
+  ai += row_carry_31(ai) + vi;
   re = fma(pr, ar, -pi * ai);                                         // p (...)
   im = fma(pr, ai, pi * ar);
 }

@@ -159,16 +159,27 @@ template <int L>
 __device__ __forceinline__ double read_lane(double v) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), L), __builtin_amdgcn_readlane(__double2loint(v), L));
 }
+// The carries between the four rows of 16 lanes of a scan, as two DPP broadcasts: lane 15 of rows 0 and 2 to rows
+// 1 and 3 (row_bcast:15, row mask 0xA), then lane 31 -- by then the total of rows 0..1 -- to rows 2 and 3
+// (row_bcast:31, row mask 0xC); the rows outside the mask read 0.  (Through the scalar registers the same took
+// six lane reads, a chain of selects per lane and the scalar unit's turn-around.)
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_rows_d0(double v) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xF, false),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xF, false));
+}
+__device__ __forceinline__ double row_carry_15(double v) { return dpp_rows_d0<kDppRowBcast15, 0xA>(v); }
+__device__ __forceinline__ double row_carry_31(double v) { return dpp_rows_d0<kDppRowBcast31, 0xC>(v); }
+
 // inclusive prefix sum over the lanes: lane i gets v_0 + ... + v_i
 __device__ __forceinline__ double wave_prefix_sum(double v, int lane) {
   v += dpp_d0<kDppRowShr + 1>(v);
   v += dpp_d0<kDppRowShr + 2>(v);
   v += dpp_d0<kDppRowShr + 4>(v);
   v += dpp_d0<kDppRowShr + 8>(v);
-  const double r0 = read_lane<15>(v), r1 = read_lane<31>(v), r2 = read_lane<47>(v);   // row totals
-  const double o2 = r0 + r1, o3 = o2 + r2;
-  const int row = lane >> 4;
-  return v + (row == 0 ? 0. : row == 1 ? r0 : row == 2 ? o2 : o3);
+  v += row_carry_15(v);
+  return v + row_carry_31(v);
 }
 // weighted suffix sum: lane i gets sum_{j >= i} m^(j - i) v_j (m wave-uniform)
 __device__ __forceinline__ double wave_suffix_geometric(double v, double m, int lane) {
@@ -204,12 +215,10 @@ __device__ __forceinline__ double wave_prefix_geometric(double v, double m1, dou
   v = fma(m2, dpp_d0<kDppRowShr + 2>(v), v);
   v = fma(m4, dpp_d0<kDppRowShr + 4>(v), v);
   v = fma(m8, dpp_d0<kDppRowShr + 8>(v), v);
-  // prefix totals at the last lane of rows 0, 1, 2
-  const double t0 = read_lane<15>(v);
-  const double t1 = fma(m16, t0, read_lane<31>(v));
-  const double t2 = fma(m16, t1, read_lane<47>(v));
-  const int row = lane >> 4;
-  return fma(wl, row == 0 ? 0. : row == 1 ? t0 : row == 2 ? t1 : t2, v);
+  // rows 1 and 3 take in the row before them, then rows 2 and 3 the (now complete) rows 0..1: lane l of row 3 is
+  // m^((l & 15) + 1 + 16) behind lane 31
+  v = fma(wl, row_carry_15(v), v);
+  return fma((lane >> 4) == 3 ? wl * m16 : wl, row_carry_31(v), v);
 }
 
 // the same in FP32 (one DPP move per step instead of two, 2-cycle arithmetic): for recurrences that forget
