@@ -152,10 +152,7 @@ struct FbTables {               // fbearmodel.c:57-61,182-225
   // A operands: [pair][K step][lane = row + 16 (k mod 4)], row = 8 (band in pair) + type,
   // type 0..5 = re, im of the three exponentials' enter rows, 6, 7 = re, im of the block the window ends in
   double bs_coef[kBsPairs][8][64];
-  // the filter's own coefficients on the block the window starts in: entry e = 2 q + (0 re, 1 im) of sample q
-  // at [e & 15][e >> 4] -- lane l keeps the four entries l & 15, 16 + (l & 15), ... as one 32-byte read, and a tap's
-  // coefficient reaches all lanes as a DPP row broadcast
-  double bs_left[kBsBands][16][4];
+  double bs_left[kBsBands][32][2];      // the filter's own coefficients (re, im) on the block the window starts in
   double bs_rot[kBsChains][2][2];       // chain = 3 band + i: rot = e^(j 32 w_i) and rot^J (re, im)
   double bs_pow[kBsChains][64][2];      // rot^(l + 1), l = 0..63
   double mfd_re[kMfdSteps * 64];        // the direct tile's A operands, lane = band - 24 + 16 (d - kMfdD0 - 4 s)

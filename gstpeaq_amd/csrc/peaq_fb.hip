@@ -524,30 +524,34 @@ __device__ __forceinline__ void bs_chain(double& re, double& im, double vr, doub
   im = fma(pr, ai, pi * ar);
 }
 
-// lane N of every row of 16 lanes, in all lanes of the row (v_mov_b64_dpp row_newbcast)
-template <int N>
-__device__ __forceinline__ double row_bcast(double v) {
-  return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + N, 0xF, 0xF, false));
-}
-// eight taps (samples 8 G .. 8 G + 7 of the block) of a window's first block: c = the lane's entry of the group's
-// sixteen coefficients (re, im alternating)
+// eight taps (samples 8 G .. 8 G + 7 of the block) of a window's first block.  The coefficients (re, im per tap) sit
+// in the wave's corner of LDS (bs_pair); every lane reads the same 16 bytes -- a broadcast, no bank conflict -- and
+// its own sample of the block: two LDS reads and two multiply-adds per tap.  (From the scalar cache every tap
+// waited for its own load; as DPP row broadcasts of a register each product took a move and a multiply-add.)
 template <int G>
-__device__ __forceinline__ void bs_left_group(const double* __restrict__ xl, double c, double& sr, double& si) {
+__device__ __forceinline__ void bs_left_group(const double* __restrict__ xl, const double* __restrict__ cl, double& sr,
+                                              double& si) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
   double x[8];
+  v2d c[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) x[k] = lds_rd(xl + (8 * G + k) * kWinRow);
-#define PEAQ_BS_TAP(K)                             \
-  sr = fma(row_bcast<2 * K>(c), x[K], sr);         \
-  si = fma(row_bcast<2 * K + 1>(c), x[K], si);
-  PEAQ_BS_TAP(0) PEAQ_BS_TAP(1) PEAQ_BS_TAP(2) PEAQ_BS_TAP(3) PEAQ_BS_TAP(4) PEAQ_BS_TAP(5) PEAQ_BS_TAP(6) PEAQ_BS_TAP(7)
-#undef PEAQ_BS_TAP
+  for (int k = 0; k < 8; ++k) {
+    x[k] = lds_rd(xl + (8 * G + k) * kWinRow);
+    c[k] = *(const __attribute__((address_space(3))) v2d*)(cl + 2 * (8 * G + k));
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sr = fma(c[k].x, x[k], sr);
+    si = fma(c[k].y, x[k], si);
+  }
 }
 
 // one pair of bands (2 p, 2 p + 1): their filter outputs at the tile's outputs lane = 0 .. 59 -> (yr, yi)[band in pair];
 // a holds the pair's A operands on entry and the next pair's on return
 __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* __restrict__ stg, double (*vst)[2],
-                                        const FbTables* __restrict__ fb, double* __restrict__ hist, int p, bool first_tile,
-                                        int nvs, int lane, double (&a)[8], double (&yr)[2], double (&yi)[2]) {
+                                        double* __restrict__ lcoef, const FbTables* __restrict__ fb, double* __restrict__ hist,
+                                        int p, bool first_tile, int nvs, int lane, double (&a)[8], double (&yr)[2],
+                                        double (&yi)[2]) {
   const int j = lane & 15, kk = lane >> 4;
   // the tables' uniform entries travel through the scalar cache (constant address space)
   kint* t_head = (kint*)(const void*)fb->bs_col_head;
@@ -558,14 +562,14 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
   const int col_head = t_head[p];
   // the history of the pair's twelve rows: lane i < J holds enter(i - J); requested first, used after the matrix work
   double h[2][6];
-  double4 cl[2];                                       // the first blocks' coefficients (bs_left)
+  double cl[2];                                        // the first blocks' coefficients (bs_left): 64 doubles per band
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub) {
     const int b = 2 * p + sub;
     const bool has = lane < t_whole[b];
 #pragma unroll
     for (int r = 0; r < 6; ++r) h[sub][r] = has ? hist[(b * 6 + r) * kBsHist + lane] : 0.;
-    cl[sub] = *reinterpret_cast<const double4*>(fb->bs_left[b][j]);
+    cl[sub] = (&fb->bs_left[b][0][0])[lane];
   }
   // r^(lane + 1) of the six chains, and r^J through the scalar cache (constant address space): all in flight during
   // the matrix work (requested where they are used, every chain waited for its own)
@@ -597,6 +601,8 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
 #pragma unroll
       for (int i = 0; i < 4; ++i) stg[ih[i] + 16 * nt] = acc[nt][i];
   }
+  lcoef[lane] = cl[0];                                 // the first blocks' coefficients where every lane can read them
+  lcoef[64 + lane] = cl[1];
   wave_lds_fence();
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub) {
@@ -607,10 +613,11 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
     {
       const double* xl = win + t_left[b] + lane;
       const int g0 = t_q0[b] >> 3;                     // (whole groups of eight in front of the window are skipped)
-      if (g0 <= 0) bs_left_group<0>(xl, cl[sub].x, sr, si);
-      if (g0 <= 1) bs_left_group<1>(xl, cl[sub].y, sr, si);
-      if (g0 <= 2) bs_left_group<2>(xl, cl[sub].z, sr, si);
-      bs_left_group<3>(xl, cl[sub].w, sr, si);
+      const double* lc = lcoef + 64 * sub;
+      if (g0 <= 0) bs_left_group<0>(xl, lc, sr, si);
+      if (g0 <= 1) bs_left_group<1>(xl, lc, sr, si);
+      if (g0 <= 2) bs_left_group<2>(xl, lc, sr, si);
+      bs_left_group<3>(xl, lc, sr, si);
     }
     double hn[6];                                      // what the history will hold after this tile
 #pragma unroll
@@ -1052,8 +1059,9 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
 #pragma unroll 1
       for (int q = 0; q < 3; ++q) {
         double pr[2], pi[2];
-        bs_pair(reinterpret_cast<const double*>(sh.win.v), stg, sh.vst, fb, &st->bs_hist[0][0][0], wv + 4 * q, b0 == 0, nvs,
-                lane, bs_a, pr, pi);
+        // (e1, ex are idle until phase 4: 128 doubles of them per wave hold a pair's left-edge coefficients)
+        bs_pair(reinterpret_cast<const double*>(sh.win.v), stg, sh.vst, &sh.e1[0][0] + 128 * wv, fb, &st->bs_hist[0][0][0],
+                wv + 4 * q, b0 == 0, nvs, lane, bs_a, pr, pi);
 #pragma unroll
         for (int k = 0; k < 3; ++k)                    // (uniform selects: the loop is not unrolled, y stays in registers)
 #pragma unroll

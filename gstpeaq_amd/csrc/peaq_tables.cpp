@@ -320,12 +320,7 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
         }
         own(32 * cR[b] + q - 727, row[6], row[7]);
         for (int ty = 0; ty < 8; ++ty) fb.bs_coef[p][q / 4][(8 * sub + ty) + 16 * (q & 3)] = row[ty];
-        {
-          double lr, li;
-          own(32 * cL[b] + q - 727, lr, li);
-          fb.bs_left[b][(2 * q) & 15][(2 * q) >> 4] = lr;
-          fb.bs_left[b][(2 * q + 1) & 15][(2 * q + 1) >> 4] = li;
-        }
+        own(32 * cL[b] + q - 727, fb.bs_left[b][q][0], fb.bs_left[b][q][1]);
       }
       for (int i = 0; i < 3; ++i) {
         for (int k = 0; k < 2; ++k) {
@@ -475,8 +470,8 @@ double fb_tables_selfcheck() {
         yr[t] += row_dot(6, ch);
         yi[t] += row_dot(7, ch);
         for (int q = fb.bs_left_q0[b]; q < 32; ++q) {
-          yr[t] += fb.bs_left[b][(2 * q) & 15][(2 * q) >> 4] * x[32 * cl + q];
-          yi[t] += fb.bs_left[b][(2 * q + 1) & 15][(2 * q + 1) >> 4] * x[32 * cl + q];
+          yr[t] += fb.bs_left[b][q][0] * x[32 * cl + q];
+          yi[t] += fb.bs_left[b][q][1] * x[32 * cl + q];
         }
       }
     } else {
