@@ -67,7 +67,6 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
   const unsigned n_sig = sig ? (a.n_test ? a.n_test[pair] : a.n_uniform_test)
                              : (a.n_ref ? a.n_ref[pair] : a.n_uniform_ref);
   const unsigned n_blocks = a.n_blocks ? a.n_blocks[pair] : a.n_blocks_uniform;
-  const float* __restrict__ x = (sig ? a.test : a.ref) + (size_t)pair * a.pair_stride * a.channels + chan;
   const long long off = sig ? a.off_test : a.off_ref;
   const size_t row_len = a.hp_row_stride;
   double* __restrict__ rows = a.hp_scratch;
@@ -112,38 +111,91 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
   HpWalk fin = w;
   double peak = 0., peak_fin = 0.;                   // largest |filtered sample| of this signal's blocks
 
-  // samples are fetched 16 ahead of their use: the walk itself is a chain of dependent FP64
-  // operations, the loads (one cache line per lane) must never be waited for
-  auto fetch = [&](unsigned bl, int k, bool mine) -> float {
-    const long long s = (long long)(blk0 + bl - origin) * kFbFrame + off + k;
-    return (mine && s < (long long)n_sig) ? x[s * a.channels] : 0.f;   // zero padding: gstpeaq.c:733-738
-  };
-  float xq[16];
+  // The input: CHUNKS of 16 samples, one chunk ahead of their use (the walk is a chain of dependent FP64 operations:
+  // the loads must never be waited for).  A chunk of a (pair, signal) row is 64 C contiguous bytes (C channels
+  // interleaved); the wave fetches the chunks of all its rows as 16-byte pieces -- four per lane, eight lanes' pieces
+  // per cache line -- parks them in LDS and every lane picks its channel's 16 samples there.  (One dword per lane
+  // and sample, as before: 64 different cache lines per load instruction, a 64-bit address and a bounds check per
+  // sample -- a quarter of the kernel's instructions.)
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  const int C = a.channels;
+  const int kInStride = C == 2 ? 34 : 18;            // floats per row in LDS: 16 C samples + padding (8-byte rows; the
+                                                     // channels' reads fall on different banks, two-way at worst)
+  const int ld_row = lane / C, ld_piece0 = 4 * (lane % C);            // the row this lane fetches for, its first piece
+  const unsigned ld_gg = g0 + (unsigned)((ld_row >> 1) * C) * 2u + (unsigned)(ld_row & 1);   // that row's channel-0 signal
+  const bool ld_live = ld_gg < n_signals;
+  const unsigned ld_pair = (ld_live ? ld_gg : n_signals - 1) / (2 * C);
+  const float* __restrict__ ld_base = ((ld_row & 1) ? a.test : a.ref) + (size_t)ld_pair * a.pair_stride * C;
+  const long long ld_len = (long long)a.pair_stride * C;              // floats in a row
+  // sample index (in its row) of sample 0 of the launch's block bl: the same for every pair (broker launches:
+  // blk0 == origin; batch launches: both uniform)
+  const long long s_first = (long long)(blk0 - origin) * kFbFrame;
+  const long long ld_s0 = s_first + ((ld_row & 1) ? a.off_test : a.off_ref);
+  const long long my_s0 = s_first + off;
+  // fast chunks: inside every lane's signal and block count (no zero padding, gstpeaq.c:733-738, to apply)
+  unsigned n_min = live ? n_sig : 0xFFFFFFFFu, nb_min = live ? nb_mine : 0u;
+  if (!live) nb_min = 0;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) xq[j] = fetch(0, j, 0 < nb_mine);
+  for (int d = 32; d >= 1; d >>= 1) {
+    n_min = min(n_min, (unsigned)__shfl_xor((int)n_min, d, 64));
+    nb_min = min(nb_min, (unsigned)__shfl_xor((int)nb_min, d, 64));
+  }
+  const unsigned n_chunks = nb_max * (kFbFrame / 16);
+  auto load_chunk = [&](unsigned c, f4u (&v)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long f = (ld_s0 + 16ll * c) * C + 4 * (ld_piece0 + j);    // first float of the piece in its row
+      f4u t = {0.f, 0.f, 0.f, 0.f};
+      if (ld_live && c < n_chunks && f >= 0) {
+        if (f + 4 <= ld_len) {
+          t = *reinterpret_cast<const f4u*>(ld_base + f);
+        } else {                                                        // the row ends inside the piece
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (f + e < ld_len) t[e] = ld_base[f + e];
+        }
+      }
+      v[j] = t;
+    }
+  };
+  __shared__ float inbuf[64 * 18];
+  f4u nxt[4];
+  load_chunk(0, nxt);
+  const int in_at = (2 * (lane / (2 * C)) + sig) * kInStride + chan;       // this lane's first sample of a chunk in LDS
   for (unsigned bl = 0; bl < nb_max; ++bl) {
     const bool mine = bl < nb_mine;
     float sum = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;   // |x| of the last five samples
     int above = 0;
-    for (int k0 = 0; k0 < kFbFrame; k0 += 8) {
+    for (int kc = 0; kc < kFbFrame / 16; ++kc) {
+      const unsigned c = bl * (kFbFrame / 16) + kc;
+      // this chunk (requested a chunk ago) into LDS, out again by channel; the next one requested
+      float xc[16];
+      {
+        float* dst = inbuf + ld_row * kInStride + 4 * ld_piece0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          reinterpret_cast<float2*>(dst + 4 * j)[0] = make_float2(nxt[j][0], nxt[j][1]);
+          reinterpret_cast<float2*>(dst + 4 * j)[1] = make_float2(nxt[j][2], nxt[j][3]);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) xc[k] = inbuf[in_at + k * C];
+        wave_lds_fence();
+        load_chunk(c + 1, nxt);
+        const long long s_c = my_s0 + 16ll * c;
+        if (!(bl < nb_min && s_c + 16 <= (long long)n_min)) {            // (wave-uniform) zero padding / idle lanes
+#pragma unroll
+          for (int k = 0; k < 16; ++k) xc[k] = (mine && s_c + k >= 0 && s_c + k < (long long)n_sig) ? xc[k] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+      const int k0 = 16 * kc + 8 * half;
       double y[8];
-      float xin[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        xin[j] = xq[j];
-        xq[j] = xq[j + 8];
-      }
-      {                                              // refill: samples k0+16 .. k0+23 (may be the next block)
-        const int kn = k0 + 16;
-        const unsigned bln = kn < kFbFrame ? bl : bl + 1;
-        const int kk = kn < kFbFrame ? kn : kn - kFbFrame;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xq[8 + j] = fetch(bln, kk + j, bln < nb_mine);
-      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = k0 + j;
-        const float xv = xin[j];
+        const float xv = xc[8 * half + j];
         y[j] = w.step((double)xv * a.level_factor);
         peak = fmax(peak, fabs(y[j]));
         // gstpeaq.c:1083-1096: FLOAT running sum, tested from i = 5 on
@@ -172,6 +224,7 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
           rows[(size_t)row_s * row_len + kFbRing + (size_t)bl * kFbFrame + k0 + (lane & 7)] = tile[src][lane & 7];
       }
       wave_lds_fence();
+      }
     }
     if (mine && sig == 0)
       a.records[((size_t)(pair * a.blocks_per_launch + bl) * a.channels + chan) * kFbRecDoubles + kFbRecFlags] =
