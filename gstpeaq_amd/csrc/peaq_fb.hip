@@ -54,10 +54,22 @@ struct HpWalk {
   }
 };
 
-__global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_signals) {
-  __shared__ double tile[64][9];                    // [signal in wave][8 samples], padded
-  const int lane = threadIdx.x;
-  const unsigned g0 = blockIdx.x * 64;
+// Workgroups of kHpWaves INDEPENDENT waves.  Beside the FP64 engine's bank kernel -- whose two workgroups fill a CU's
+// registers and LDS -- a workgroup of this kernel takes the place of one of them for as long as the walk lasts: in
+// workgroups of one wave the dispatcher spreads a 4096-pair batch's 256 waves over 256 CUs, in workgroups of four
+// (one wave per SIMD) over 64.  Measured, 4096 pairs, advanced pass of the FP64 engine: 1 wave 413-416 ms, 2: 409,
+// 4: 404, 8: 418 (the walk itself then takes longer than the bank launch it has to finish beside).
+#ifndef PEAQ_HP_WAVES
+#define PEAQ_HP_WAVES 4
+#endif
+constexpr int kHpWaves = PEAQ_HP_WAVES;
+__global__ __launch_bounds__(64 * kHpWaves) void fb_hp_kernel(FbFrontArgs a, unsigned n_signals) {
+  __shared__ double tiles[kHpWaves][64][9];         // per wave: [signal in wave][8 samples], padded
+  __shared__ float inbufs[kHpWaves][64 * 18];
+  const int lane = threadIdx.x & 63;
+  double (*tile)[9] = tiles[threadIdx.x >> 6];
+  float* inbuf = inbufs[threadIdx.x >> 6];
+  const unsigned g0 = blockIdx.x * (64 * kHpWaves) + (threadIdx.x & ~63u);
   const unsigned g = g0 + lane;
   const bool live = g < n_signals;
   const unsigned gg = live ? g : n_signals - 1;
@@ -158,7 +170,6 @@ __global__ __launch_bounds__(64) void fb_hp_kernel(FbFrontArgs a, unsigned n_sig
       v[j] = t;
     }
   };
-  __shared__ float inbuf[64 * 18];
   f4u nxt[4];
   load_chunk(0, nxt);
   const int in_at = (2 * (lane / (2 * C)) + sig) * kInStride + chan;       // this lane's first sample of a chunk in LDS
@@ -1358,7 +1369,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(100))) void 
 hipError_t launch_fb_hp(const FbFrontArgs& a, unsigned n_pairs, hipStream_t stream) {
   const unsigned n_signals = n_pairs * a.channels * 2;
   if (n_signals == 0 || a.blocks_per_launch == 0) return hipSuccess;
-  hipLaunchKernelGGL(fb_hp_kernel, dim3((n_signals + 63) / 64), dim3(64), 0, stream, a, n_signals);
+  hipLaunchKernelGGL(fb_hp_kernel, dim3((n_signals + 64 * kHpWaves - 1) / (64 * kHpWaves)), dim3(64 * kHpWaves), 0, stream, a,
+                     n_signals);
   return hipGetLastError();
 }
 
