@@ -1258,13 +1258,17 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     FB_MARK(7);
     // ---- phase 3: downward spreading (fbearmodel.c:351-354): wave 0 the real, wave 1 the
     // imaginary parts; a column per lane ----------------------------------------------------------
+    // (the column is read into registers first: as a loop of read - multiply-add - write the 39 steps each waited
+    // for their own LDS round trip, 4.7 k cycles for 39 multiply-adds while the other two waves stood at the barrier)
     if (wv < 2) {
       double (*A)[kACols] = wv == 0 ? sh.a.re : sh.a.im;
-      double acc = A[kFbBands - 1][lane];
-#pragma unroll 13
+      double col[kFbBands];
+#pragma unroll
+      for (int b = 0; b < kFbBands; ++b) col[b] = A[b][lane];
+#pragma unroll
       for (int b = kFbBands - 1; b > 0; --b) {
-        acc = A[b - 1][lane] + kCL * acc;
-        A[b - 1][lane] = acc;
+        col[b - 1] = col[b - 1] + kCL * col[b];
+        A[b - 1][lane] = col[b - 1];
       }
     }
     __syncthreads();
