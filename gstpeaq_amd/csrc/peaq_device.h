@@ -19,6 +19,11 @@ constexpr int kFbFrame    = 192;    // fbearmodel.c:48
 constexpr int kFbBands    = 40;
 constexpr int kFbRing     = 1456;   // fbearmodel.c:52
 constexpr int kFbTaps     = 11;     // backward-masking FIR history (fbearmodel.c:262)
+// its taps 0..5 (the filter is symmetric), cos^2(pi (i - 5) / 12) 0.9761 / 6 (fbearmodel.c:182-185) as the host's libm
+// rounds them -- compile-time constants in the kernel (read from FbTables every tile's 12 requests stood in the way of
+// the phase's LDS reads); peaq_tables.cpp checks them against its own evaluation
+constexpr double kBackMask[6] = {0x1.6518acf1cfa3cp-7, 0x1.4d2ceb622adf4p-5, 0x1.4d2ceb622adf3p-4,
+                                 0x1.f3c36113404ebp-4, 0x1.36db60930de4ep-3, 0x1.4d2ceb622adf1p-3};
 // Filter bank on the matrix cores.  All 40 filters are centred on the same delay
 // (D + N/2 = 729 samples) and h(N - n) = conj(h(n)), so the bank is two GEMMs over the delays
 // d = 1..729 only: the real parts against x[t-d] + x[t-(1458-d)], the imaginary parts against

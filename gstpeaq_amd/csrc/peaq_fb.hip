@@ -1073,6 +1073,9 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
 #ifdef PEAQ_FB_PROFILE
   unsigned long long prof_t_ = __builtin_readcyclecounter();
 #endif
+  // per-thread and uniform constants of the tile loop, fetched once (inside, every tile waited for them again)
+  const double fm_noise = tid < kFbBands ? bt->internal_noise[tid] : 0., fm_ac = tid < kFbBands ? bt->ear_tc[tid] : 0.;
+  const double alias_re = fb->h_re[1], alias_im = fb->h_im[1];
   const int tid_k = tid, lane_k = lane, wv_k = wv;
   for (unsigned b0 = 0; b0 < nb_mine; b0 += kTileBlocks) {
     // The thread's indices are re-derived (as far as the compiler can tell) in every tile: otherwise it computes the
@@ -1174,8 +1177,8 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
       // (the doubled ring buffer makes fb_buf[offset + 1456] alias fb_buf[offset], fbearmodel.c:413-414)
       const int tt = lane < kTileSub ? lane : kTileSub - 1;
       const double delta = sh.win.get(kFbRing + 32 * tt, xus) - sh.win.get(32 * tt, xus);
-      re[0] = fma(fb->h_re[1], delta, re[0]);
-      im[0] = fma(-fb->h_im[1], delta, im[0]);
+      re[0] = fma(alias_re, delta, re[0]);
+      im[0] = fma(-alias_im, delta, im[0]);
       sh.a.re[0][lane] = re[0];                      // band 0 is nobody's spreading target
       sh.a.im[0][lane] = im[0];
     }
@@ -1233,7 +1236,9 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         const double v = wave_prefix_geometric(sg * dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
         cu = v + decay * sh.cu[b];
       }
-      const double carry = __shfl(cu, nvs - 1, 64);
+      // the state after the tile's last valid time point goes on (a lane read through the scalar unit: nvs is uniform)
+      const double carry = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cu), nvs - 1),
+                                            __builtin_amdgcn_readlane(__double2loint(cu), nvs - 1));
       if (lane == 0) sh.cu[b] = carry;                               // only this wave touches cu[b]
       cuv[i] = (decltype(cuv[0] + 0))cu;
     }
@@ -1296,8 +1301,8 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         const int s_new = 6 * k + 5;                 // newest sub-sample of block k
         double e1 = 0.;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) e1 += (e0(s_new - t) + e0(s_new - 10 + t)) * fb->back_mask[t];
-        e1 += e0(s_new - 5) * fb->back_mask[5];
+        for (int t = 0; t < 5; ++t) e1 += (e0(s_new - t) + e0(s_new - 10 + t)) * kBackMask[t];
+        e1 += e0(s_new - 5) * kBackMask[5];
         sh.e1[b][k] = e1;
         // history for the next tile: the 10 newest VALID sub-samples, oldest first
         hnew[rep] = e0(nvs - 10 + k);
@@ -1315,7 +1320,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     // ---- phase 5: internal noise + forward masking (fbearmodel.c:385-394).  The recurrence along
     // the blocks is walked by one thread per band into LDS; then all threads write the records --------
     if (tid < kFbBands) {
-      const double noise = bt->internal_noise[tid], ac = bt->ear_tc[tid];
+      const double noise = fm_noise, ac = fm_ac;
       for (unsigned bl = 0; bl < nvb; ++bl) {
         const double unsm = sh.e1[tid][bl] + noise;
         exc = ac * exc + (1. - ac) * unsm;

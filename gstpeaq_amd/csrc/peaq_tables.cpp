@@ -339,7 +339,8 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
   for (int k = 0; k < 6; ++k) {
     const double c = std::cos(kPi * (k - 5.0) / 12.0);
     fb.back_mask[k] = c * c * 0.9761 / 6.0;
-  }
+    if (std::fabs(fb.back_mask[k] - kBackMask[k]) > 4e-17 * kBackMask[k]) std::abort();   // peaq_device.h (a last-bit difference
+  }                                                                                        // of another libm is as good)
   fill_common_bands(t, fc, kFbFrame, 1.26539, 0.004, 0.020);  // fbearmodel.c:171-177
   t.delta_z = 0.0;
 }
