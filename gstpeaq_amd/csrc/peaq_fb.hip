@@ -1213,9 +1213,21 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     // inside an instruction) ------------------------------------------------------------------------
     // (the reduced-precision engine spreads in FP32: it keeps the ten slopes as floats)
     typename std::conditional<sizeof(WT) == 2, float, double>::type cuv[10];
+    // FP64 engines: the ten bands' exp(min(., . + C1 ln |A|^2)) five at a time in lockstep (log_nonneg_n)
+    double dist_s5[sizeof(WT) == 2 ? 1 : 5];
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       const int b = wave_band(wv, i);
+      if constexpr (sizeof(WT) != 2) {
+        if (i % 5 == 0) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) dist_s5[k] = re[i + k] * re[i + k] + im[i + k] * im[i + k];
+          log_nonneg_n<5>(dist_s5);
+#pragma unroll
+          for (int k = 0; k < 5; ++k) dist_s5[k] = fmin(4. * kLnDist, sh.c0[wave_band(wv, i + k)] + kC1 * dist_s5[k]);
+          exp_fast_n<5>(dist_s5);
+        }
+      }
       // pow(DIST, s), s = max(4, 24 + 230/fc - 0.2 L), L = 10 log10 |A|^2 (fbearmodel.c:329-333), as
       // exp(min(4 ln DIST, ln DIST (24 + 230/fc) - 2 ln DIST / ln 10 * ln |A|^2))  (ln DIST < 0)
       double cu;
@@ -1232,7 +1244,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         const double v = wave_prefix_geometric(sg * (double)dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
         cu = fma(decay, sh.cu[b], v);
       } else {
-        const double dist_s = exp_fast(fmin(4. * kLnDist, sh.c0[b] + kC1 * log_nonneg(re[i] * re[i] + im[i] * im[i])));
+        const double dist_s = dist_s5[i % 5];
         const double v = wave_prefix_geometric(sg * dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
         cu = v + decay * sh.cu[b];
       }

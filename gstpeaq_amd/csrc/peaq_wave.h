@@ -288,13 +288,36 @@ __device__ __forceinline__ int wave_or_i(int v) {
 // arguments for the logarithm -- against a parity bar of 1e-7 (tools/check_math.hip measures them
 // against OCML on the GPU).
 
+// A double constant placed in a scalar register pair by two s_mov_b32.  The filter bank's FP64 kernel is at its
+// register budget: there the compiler kept these polynomial coefficients in vector registers across the tile loop
+// and spilled them to scratch; scalar copies cost no vector register and at worst a v_readlane to bring back.
+template <long long BITS> __device__ __forceinline__ double scalar_const() {
+  unsigned lo, hi;
+  asm("s_mov_b32 %0, %1" : "=s"(lo) : "i"((unsigned)(BITS & 0xffffffffll)));
+  asm("s_mov_b32 %0, %1" : "=s"(hi) : "i"((unsigned)((unsigned long long)BITS >> 32)));
+  return __hiloint2double((int)hi, (int)lo);
+}
+#define PEAQ_KC(c) (SK ? scalar_const<__builtin_bit_cast(long long, (double)(c))>() : (double)(c))
+// a * b + c with c such a scalar constant: written out because the compiler would select the two-address v_fmac_f64
+// here and pay two v_mov_b32 per Horner step to move the constant into the accumulator first
+template <bool SK, long long BITS> __device__ __forceinline__ double fma_const(double a, double b) {
+  if constexpr (SK) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(scalar_const<BITS>()));
+    return r;
+  } else {
+    return fma(a, b, __builtin_bit_cast(double, BITS));
+  }
+}
+#define PEAQ_FMA_KC(a, b, c) fma_const<SK, __builtin_bit_cast(long long, (double)(c))>(a, b)
+
 // ln x for finite x > 0 (subnormals included).  x = m 2^e with m in [sqrt(1/2), sqrt(2));
 // ln m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716: odd series up to s^19 (truncation
 // < 2e-17 relative); e ln 2 is added as a 32-bit high part (exact product) plus a low part.
-__device__ __forceinline__ double log_pos(double x) {
+template <bool SK = false> __device__ __forceinline__ double log_pos(double x) {
   double m = __builtin_amdgcn_frexp_mant(x);         // [0.5, 1)
   int e = __builtin_amdgcn_frexp_exp(x);
-  const bool low = m < 0.70710678118654752440;
+  const bool low = m < PEAQ_KC(0.70710678118654752440);
   m = low ? m + m : m;
   e = low ? e - 1 : e;
   const double num = m - 1., den = m + 1.;           // both exact
@@ -303,19 +326,19 @@ __device__ __forceinline__ double log_pos(double x) {
   double s = num * r;                                // quotient with one residual correction (error x error)
   s = fma(fma(-den, s, num), r, s);
   const double z = s * s;
-  double p = 1. / 19;
-  p = fma(p, z, 1. / 17);
-  p = fma(p, z, 1. / 15);
-  p = fma(p, z, 1. / 13);
-  p = fma(p, z, 1. / 11);
-  p = fma(p, z, 1. / 9);
-  p = fma(p, z, 1. / 7);
-  p = fma(p, z, 1. / 5);
-  p = fma(p, z, 1. / 3);
+  double p = PEAQ_KC(1. / 19);
+  p = PEAQ_FMA_KC(p, z, 1. / 17);
+  p = PEAQ_FMA_KC(p, z, 1. / 15);
+  p = PEAQ_FMA_KC(p, z, 1. / 13);
+  p = PEAQ_FMA_KC(p, z, 1. / 11);
+  p = PEAQ_FMA_KC(p, z, 1. / 9);
+  p = PEAQ_FMA_KC(p, z, 1. / 7);
+  p = PEAQ_FMA_KC(p, z, 1. / 5);
+  p = PEAQ_FMA_KC(p, z, 1. / 3);
   const double t = s + s;
   const double lm = fma(t * z, p, t);                // 2 s (1 + z P(z))
   const double ef = (double)e;
-  return fma(ef, 6.93147180369123816490e-01, fma(ef, 1.90821492927058770002e-10, lm));
+  return fma(ef, PEAQ_KC(6.93147180369123816490e-01), fma(ef, PEAQ_KC(1.90821492927058770002e-10), lm));
 }
 
 // ln x for finite x > 0 (subnormals included) from the 129-entry table CommonTables::log_tab, which the caller
@@ -360,32 +383,110 @@ __device__ __forceinline__ double log_tab_nonneg(double x, const double* __restr
 
 // the same for any x >= 0 or NaN: ln 0 = -inf, ln inf = inf (digital silence reaches the
 // logarithms of the error-harmonic-structure and of the filter-bank slope computation)
-__device__ __forceinline__ double log_nonneg(double x) {
-  const double l = log_pos(x);
+template <bool SK = false> __device__ __forceinline__ double log_nonneg(double x) {
+  const double l = log_pos<SK>(x);
   return x == 0. ? -__builtin_inf() : (x == __builtin_inf() ? __builtin_inf() : l);
 }
 
 // e^x for any finite x or -inf (underflows to 0, overflows to inf through ldexp).
 // x = n ln 2 + r, |r| <= 0.3466; e^r as its Taylor polynomial of degree 12 (truncation 1.7e-16).
-__device__ __forceinline__ double exp_fast(double x) {
+template <bool SK = false> __device__ __forceinline__ double exp_fast(double x) {
   x = fmin(fmax(x, -1000.), 1000.);
-  const double n = __builtin_rint(x * 1.44269504088896338700e+00);
-  double r = fma(-n, 6.93147180369123816490e-01, x);
-  r = fma(-n, 1.90821492927058770002e-10, r);
-  double p = 1. / 479001600.;
-  p = fma(p, r, 1. / 39916800.);
-  p = fma(p, r, 1. / 3628800.);
-  p = fma(p, r, 1. / 362880.);
-  p = fma(p, r, 1. / 40320.);
-  p = fma(p, r, 1. / 5040.);
-  p = fma(p, r, 1. / 720.);
-  p = fma(p, r, 1. / 120.);
-  p = fma(p, r, 1. / 24.);
-  p = fma(p, r, 1. / 6.);
+  const double n = __builtin_rint(x * PEAQ_KC(1.44269504088896338700e+00));
+  double r = fma(-n, PEAQ_KC(6.93147180369123816490e-01), x);
+  r = fma(-n, PEAQ_KC(1.90821492927058770002e-10), r);
+  double p = PEAQ_KC(1. / 479001600.);
+  p = PEAQ_FMA_KC(p, r, 1. / 39916800.);
+  p = PEAQ_FMA_KC(p, r, 1. / 3628800.);
+  p = PEAQ_FMA_KC(p, r, 1. / 362880.);
+  p = PEAQ_FMA_KC(p, r, 1. / 40320.);
+  p = PEAQ_FMA_KC(p, r, 1. / 5040.);
+  p = PEAQ_FMA_KC(p, r, 1. / 720.);
+  p = PEAQ_FMA_KC(p, r, 1. / 120.);
+  p = PEAQ_FMA_KC(p, r, 1. / 24.);
+  p = PEAQ_FMA_KC(p, r, 1. / 6.);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.);
   p = fma(p, r, 1.);
   return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
+// N independent arguments in lockstep with the polynomial constants in scalar registers (the filter bank's FP64
+// kernel: ten bands of one time point per lane).  The same operations in the same order as log_nonneg<true> and
+// exp_fast<true> on each element, so the results are theirs bit for bit; what changes is that a constant is
+// set up once per Horner step rather than once per step AND element (two s_mov_b32 each, and a wave issues
+// scalar and vector instructions in order), and that the N chains are independent of each other.
+__device__ __forceinline__ double fma_sgpr(double a, double b, double c_scalar) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_scalar));
+  return r;
+}
+#define PEAQ_SC(c) scalar_const<__builtin_bit_cast(long long, (double)(c))>()
+template <int N> __device__ __forceinline__ void log_nonneg_n(double (&x)[N]) {
+  double s[N], z[N], p[N], ef[N];
+  const double rt = PEAQ_SC(0.70710678118654752440);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double m = __builtin_amdgcn_frexp_mant(x[i]);
+    int e = __builtin_amdgcn_frexp_exp(x[i]);
+    const bool low = m < rt;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double num = m - 1., den = m + 1.;
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.), r, r);
+    double q = num * r;
+    q = fma(fma(-den, q, num), r, q);
+    s[i] = q;
+    z[i] = q * q;
+    ef[i] = (double)e;
+  }
+  {
+    const double c = PEAQ_SC(1. / 19);
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = c;
+  }
+#define PEAQ_STEP(v, cc)                                          \
+  {                                                               \
+    const double c = PEAQ_SC(cc);                                 \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) p[i] = fma_sgpr(p[i], v[i], c); \
+  }
+  PEAQ_STEP(z, 1. / 17) PEAQ_STEP(z, 1. / 15) PEAQ_STEP(z, 1. / 13) PEAQ_STEP(z, 1. / 11)
+  PEAQ_STEP(z, 1. / 9) PEAQ_STEP(z, 1. / 7) PEAQ_STEP(z, 1. / 5) PEAQ_STEP(z, 1. / 3)
+  const double ln2h = PEAQ_SC(6.93147180369123816490e-01), ln2l = PEAQ_SC(1.90821492927058770002e-10);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double t = s[i] + s[i];
+    const double lm = fma(t * z[i], p[i], t);
+    const double l = fma(ef[i], ln2h, fma(ef[i], ln2l, lm));
+    x[i] = x[i] == 0. ? -__builtin_inf() : (x[i] == __builtin_inf() ? __builtin_inf() : l);
+  }
+}
+template <int N> __device__ __forceinline__ void exp_fast_n(double (&x)[N]) {
+  double r[N], p[N], n[N];
+  const double il2 = PEAQ_SC(1.44269504088896338700e+00);
+  const double ln2h = PEAQ_SC(6.93147180369123816490e-01), ln2l = PEAQ_SC(1.90821492927058770002e-10);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double xx = fmin(fmax(x[i], -1000.), 1000.);
+    n[i] = __builtin_rint(xx * il2);
+    r[i] = fma(-n[i], ln2l, fma(-n[i], ln2h, xx));
+  }
+  {
+    const double c = PEAQ_SC(1. / 479001600.);
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = c;
+  }
+  PEAQ_STEP(r, 1. / 39916800.) PEAQ_STEP(r, 1. / 3628800.) PEAQ_STEP(r, 1. / 362880.) PEAQ_STEP(r, 1. / 40320.)
+  PEAQ_STEP(r, 1. / 5040.) PEAQ_STEP(r, 1. / 720.) PEAQ_STEP(r, 1. / 120.) PEAQ_STEP(r, 1. / 24.) PEAQ_STEP(r, 1. / 6.)
+#undef PEAQ_STEP
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double q = fma(p[i], r[i], 0.5);
+    q = fma(q, r[i], 1.);
+    q = fma(q, r[i], 1.);
+    x[i] = __builtin_amdgcn_ldexp(q, (int)n[i]);
+  }
 }
 
 // a / b for finite b of moderate magnitude (no scaling against overflow / underflow of the
