@@ -569,7 +569,8 @@ __device__ __forceinline__ void bs_tile(const double* __restrict__ win, const do
 // from (pr, pi) = r^(lane + 1) alone: every input is turned back into the frame of output -1 (times conj r^(s+1)),
 // the frame's plain prefix sum is taken (DPP row shifts and row broadcasts) and
 // turned forward again.  |r| = 1: the turns cost no accuracy.
-__device__ __forceinline__ void bs_chain(double& re, double& im, double vr, double vi, double pr, double pi, int lane) {
+__device__ __forceinline__ void bs_chain(double& re, double& im, double vr, double vi, double pr, double pi, int lane,
+                                         double& z15, double& z31) {
   double ar = fma(pr, re, pi * im), ai = fma(pr, im, -pi * re);       // conj(p) u
 #define PEAQ_BS_LEVEL(SH)                    \
   ar += dpp_d0<kDppRowShr + SH>(ar);         \
@@ -580,10 +581,10 @@ __device__ __forceinline__ void bs_chain(double& re, double& im, double vr, doub
   PEAQ_BS_LEVEL(8)
 #undef PEAQ_BS_LEVEL
   // what came before a row: the rows in front of it (two DPP broadcasts, peaq_wave.h) and v
-  ar += row_carry_15(ar);
-  ai += row_carry_15(ai);
-  ar += row_carry_31(ar) + vr;
-  ai += row_carry_31(ai) + vi;
+  ar += row_carry_15(ar, z15);
+  ai += row_carry_15(ai, z15);
+  ar += row_carry_31(ar, z31) + vr;
+  ai += row_carry_31(ai, z31) + vi;
   re = fma(pr, ar, -pi * ai);                                         // p (...)
   im = fma(pr, ai, pi * ar);
 }
@@ -624,16 +625,19 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
   kint* t_q0 = (kint*)(const void*)fb->bs_left_q0;
   kint* t_whole = (kint*)(const void*)fb->bs_whole;
   const int col_head = t_head[p];
-  // the history of the pair's twelve rows: lane i < J holds enter(i - J); requested first, used after the matrix work
+  // the history of the pair's twelve rows: lane i < J holds enter(i - J); requested first, used after the matrix work.
+  // Lanes from J on are never looked at (a prefix sum read at lane J - 1, a select on lane < J, a shuffle from
+  // lanes < J): they load whatever the clamped index finds -- twelve loads off one address, no branches.
   double h[2][6];
   double cl[2];                                        // the first blocks' coefficients (bs_left): 64 doubles per band
+  {
+    const double* hrow = hist + (size_t)(2 * p) * 6 * kBsHist + min(lane, kBsHist - 1);
 #pragma unroll
-  for (int sub = 0; sub < 2; ++sub) {
-    const int b = 2 * p + sub;
-    const bool has = lane < t_whole[b];
+    for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-    for (int r = 0; r < 6; ++r) h[sub][r] = has ? hist[(b * 6 + r) * kBsHist + lane] : 0.;
-    cl[sub] = (&fb->bs_left[b][0][0])[lane];
+      for (int r = 0; r < 6; ++r) h[sub][r] = hrow[(sub * 6 + r) * kBsHist];
+      cl[sub] = (&fb->bs_left[2 * p + sub][0][0])[lane];
+    }
   }
   // r^(lane + 1) of the six chains, and r^J through the scalar cache (constant address space): all in flight during
   // the matrix work (requested where they are used, every chain waited for its own)
@@ -665,6 +669,7 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
 #pragma unroll
       for (int i = 0; i < 4; ++i) stg[ih[i] + 16 * nt] = acc[nt][i];
   }
+  double z15 = 0., z31 = 0.;                           // the scans' row carries land in these (dpp_rows_keep)
   lcoef[lane] = cl[0];                                 // the first blocks' coefficients where every lane can read them
   lcoef[64 + lane] = cl[1];
   wave_lds_fence();
@@ -684,21 +689,31 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
       bs_left_group<3>(xl, lc, sr, si);
     }
     double hn[6];                                      // what the history will hold after this tile
+    // V(-1) of the three chains: from the history (lane J - 1 of its sums) on a launch's first tile, else from the
+    // previous tile.  Decided once for the three, and the new V stored once after them: the chains' own work then is
+    // one basic block, and the scheduler fills each chain's DPP latencies with the other two.
+    double vr[3], vi[3];
+    if (first_tile) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        double ar = h[sub][2 * e], ai = h[sub][2 * e + 1];
+        bs_chain(ar, ai, 0., 0., pwr[3 * sub + e], pwi[3 * sub + e], lane, z15, z31);
+        vr[e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ar), J - 1),
+                                 __builtin_amdgcn_readlane(__double2loint(ar), J - 1));
+        vi[e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ai), J - 1),
+                                 __builtin_amdgcn_readlane(__double2loint(ai), J - 1));
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        vr[e] = vst[6 * p + 3 * sub + e][0];
+        vi[e] = vst[6 * p + 3 * sub + e][1];
+      }
+    }
+    double wr[3], wi[3];
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
       const int c = 3 * sub + e;
-      double vr, vi;                                   // V(-1)
-      if (first_tile) {                                // from the history: lane J - 1 of its sums
-        double ar = h[sub][2 * e], ai = h[sub][2 * e + 1];
-        bs_chain(ar, ai, 0., 0., pwr[c], pwi[c], lane);
-        vr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ar), J - 1),
-                              __builtin_amdgcn_readlane(__double2loint(ar), J - 1));
-        vi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ai), J - 1),
-                              __builtin_amdgcn_readlane(__double2loint(ai), J - 1));
-      } else {
-        vr = vst[6 * p + c][0];
-        vi = vst[6 * p + c][1];
-      }
       // enter(t) - rot^J enter(t - J)
       const bool in_tile = lane >= J;
       const double er = urow[2 * e * kStRow], ei = urow[(2 * e + 1) * kStRow];
@@ -706,22 +721,25 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
       const double pi = in_tile ? urow[(2 * e + 1) * kStRow - J] : h[sub][2 * e + 1];
       double re = fma(-rjr[c], pr, fma(rji[c], pi, er));
       double im = fma(-rjr[c], pi, fma(-rji[c], pr, ei));
-      bs_chain(re, im, vr, vi, pwr[c], pwi[c], lane);
+      bs_chain(re, im, vr[e], vi[e], pwr[c], pwi[c], lane, z15, z31);
       // the sums after the tile's last valid output go on to the next tile
-      const double wr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(re), nvs - 1),
-                                         __builtin_amdgcn_readlane(__double2loint(re), nvs - 1));
-      const double wi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(im), nvs - 1),
-                                         __builtin_amdgcn_readlane(__double2loint(im), nvs - 1));
-      if (lane == 0) {
-        vst[6 * p + c][0] = wr;
-        vst[6 * p + c][1] = wi;
-      }
+      wr[e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(re), nvs - 1),
+                               __builtin_amdgcn_readlane(__double2loint(re), nvs - 1));
+      wi[e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(im), nvs - 1),
+                               __builtin_amdgcn_readlane(__double2loint(im), nvs - 1));
       sr += re;
       si += im;
       // history: lane i < J <- enter(nvs - J + i)
       const int src = nvs - J + lane;
       hn[2 * e] = urow[2 * e * kStRow + (src >= 0 ? src : 0) - lane];
       hn[2 * e + 1] = urow[(2 * e + 1) * kStRow + (src >= 0 ? src : 0) - lane];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        vst[6 * p + 3 * sub + e][0] = wr[e];
+        vst[6 * p + 3 * sub + e][1] = wi[e];
+      }
     }
     if (nvs < J) {                                     // a short tile (the last of a launch): part of the old history stays
 #pragma unroll
@@ -1075,7 +1093,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
 #endif
   // per-thread and uniform constants of the tile loop, fetched once (inside, every tile waited for them again)
   const double fm_noise = tid < kFbBands ? bt->internal_noise[tid] : 0., fm_ac = tid < kFbBands ? bt->ear_tc[tid] : 0.;
-  const double alias_re = fb->h_re[1], alias_im = fb->h_im[1];
+  const double alias_re = ((kdouble*)(const void*)fb->h_re)[1], alias_im = ((kdouble*)(const void*)fb->h_im)[1];   // (scalar registers)
   const int tid_k = tid, lane_k = lane, wv_k = wv;
   for (unsigned b0 = 0; b0 < nb_mine; b0 += kTileBlocks) {
     // The thread's indices are re-derived (as far as the compiler can tell) in every tile: otherwise it computes the
@@ -1129,13 +1147,18 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         // (e1, ex are idle until phase 4: 128 doubles of them per wave hold a pair's left-edge coefficients)
         bs_pair(reinterpret_cast<const double*>(sh.win.v), stg, sh.vst, &sh.e1[0][0] + 128 * wv, fb, &st->bs_hist[0][0][0],
                 wv + 4 * q, b0 == 0, nvs, lane, bs_a, pr, pi);
-#pragma unroll
-        for (int k = 0; k < 3; ++k)                    // (uniform selects: the loop is not unrolled, y stays in registers)
-#pragma unroll
-          for (int sub = 0; sub < 2; ++sub) {
-            yr[k][sub] = q == k ? pr[sub] : yr[k][sub];
-            yi[k][sub] = q == k ? pi[sub] : yi[k][sub];
-          }
+        // (the loop is not unrolled -- unrolled, the scheduler lifts the next pair's loads over this one's work and
+        // spills 200 registers -- so y goes to its registers through a uniform branch)
+#define PEAQ_Y_KEEP(k)                                 \
+  yr[k][0] = pr[0], yr[k][1] = pr[1], yi[k][0] = pi[0], yi[k][1] = pi[1];
+        if (q == 0) {
+          PEAQ_Y_KEEP(0)
+        } else if (q == 1) {
+          PEAQ_Y_KEEP(1)
+        } else {
+          PEAQ_Y_KEEP(2)
+        }
+#undef PEAQ_Y_KEEP
       }
       FB_MARK(13);
       __syncthreads();                                               // every wave is done with its staging rows
@@ -1215,6 +1238,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     typename std::conditional<sizeof(WT) == 2, float, double>::type cuv[10];
     // FP64 engines: the ten bands' exp(min(., . + C1 ln |A|^2)) five at a time in lockstep (log_nonneg_n)
     double dist_s5[sizeof(WT) == 2 ? 1 : 5];
+    double z15 = 0., z31 = 0.;                       // the scans' row carries (dpp_rows_keep)
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       const int b = wave_band(wv, i);
@@ -1241,11 +1265,11 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         // The slope filter itself runs in FP64 like the reference's: it is the one recurrence ALONG the stream in
         // this phase, and in FP32 its rounding depended on where a launch (hence a tile) happened to start -- a
         // session and the batch path then disagreed in the eighth digit.  Everything per time point stays FP32.
-        const double v = wave_prefix_geometric(sg * (double)dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
+        const double v = wave_prefix_geometric(sg * (double)dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane, z15, z31);
         cu = fma(decay, sh.cu[b], v);
       } else {
         const double dist_s = dist_s5[i % 5];
-        const double v = wave_prefix_geometric(sg * dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane);
+        const double v = wave_prefix_geometric(sg * dist_s, kM1, kM2, kM4, kM8, kM16, decay_row, lane, z15, z31);
         cu = v + decay * sh.cu[b];
       }
       // the state after the tile's last valid time point goes on (a lane read through the scalar unit: nvs is uniform)

@@ -169,6 +169,17 @@ __device__ __forceinline__ double dpp_rows_d0(double v) {
   return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xF, false),
                           __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xF, false));
 }
+// The same with the zero kept in a register of the caller's: `z` starts as 0., only the rows of ROWS are ever written
+// into it, so the other rows still read 0 -- and the two moves that would set the destination to zero in front of
+// every use are gone.  One such register per ROWS mask (a scan-heavy loop saves eight moves per complex scan).
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_rows_keep(double v, double& z) {
+  z = __hiloint2double(__builtin_amdgcn_update_dpp(__double2hiint(z), __double2hiint(v), CTRL, ROWS, 0xF, false),
+                       __builtin_amdgcn_update_dpp(__double2loint(z), __double2loint(v), CTRL, ROWS, 0xF, false));
+  return z;
+}
+__device__ __forceinline__ double row_carry_15(double v, double& z) { return dpp_rows_keep<kDppRowBcast15, 0xA>(v, z); }
+__device__ __forceinline__ double row_carry_31(double v, double& z) { return dpp_rows_keep<kDppRowBcast31, 0xC>(v, z); }
 __device__ __forceinline__ double row_carry_15(double v) { return dpp_rows_d0<kDppRowBcast15, 0xA>(v); }
 __device__ __forceinline__ double row_carry_31(double v) { return dpp_rows_d0<kDppRowBcast31, 0xC>(v); }
 
@@ -219,6 +230,16 @@ __device__ __forceinline__ double wave_prefix_geometric(double v, double m1, dou
   // m^((l & 15) + 1 + 16) behind lane 31
   v = fma(wl, row_carry_15(v), v);
   return fma((lane >> 4) == 3 ? wl * m16 : wl, row_carry_31(v), v);
+}
+// the same with the row carries' zero registers kept by the caller (dpp_rows_keep)
+__device__ __forceinline__ double wave_prefix_geometric(double v, double m1, double m2, double m4, double m8, double m16,
+                                                        double wl, int lane, double& z15, double& z31) {
+  v = fma(m1, dpp_d0<kDppRowShr + 1>(v), v);
+  v = fma(m2, dpp_d0<kDppRowShr + 2>(v), v);
+  v = fma(m4, dpp_d0<kDppRowShr + 4>(v), v);
+  v = fma(m8, dpp_d0<kDppRowShr + 8>(v), v);
+  v = fma(wl, row_carry_15(v, z15), v);
+  return fma((lane >> 4) == 3 ? wl * m16 : wl, row_carry_31(v, z31), v);
 }
 
 // the same in FP32 (one DPP move per step instead of two, 2-cycle arithmetic): for recurrences that forget
