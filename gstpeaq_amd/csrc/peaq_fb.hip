@@ -1139,7 +1139,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     if constexpr (sizeof(WT) == 8) {
       // FP64 engine: bands 0 .. 23 in the block-sum form (three pairs per wave; the staging rows occupy what will
       // be A, the results wait in registers), then bands 24 .. 39 as one direct tile
-      double* stg = &sh.a.re[0][0] + wv * kStWave;
+      double* stg = (wv < 2 ? &sh.a.re[0][0] : &sh.a.im[0][0]) + (wv & 1) * kStWave;   // waves 0, 1 in the re half of A, 2, 3 in the im half
       double yr[3][2], yi[3][2];
 #pragma unroll 1
       for (int q = 0; q < 3; ++q) {
@@ -1160,6 +1160,16 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         }
 #undef PEAQ_Y_KEEP
       }
+      // Rows 24 .. 39 of A, which the direct tile adds into, lie inside the staging rows of waves 1 (re) and 3 (im):
+      // each zeroes them once it is through with its own pairs, in front of the barrier, so that no second barrier
+      // has to stand between the results below and the direct tile.
+      static_assert(kStWave <= kMfdBand0 * kACols && 2 * kStWave <= kFbBands * kACols && (kMfdBand0 * kACols) % 2 == 0 &&
+                        ((kFbBands - kMfdBand0) * kACols) % 2 == 0,
+                    "waves 0 and 2 stay below row 24 of their half, waves 1 and 3 inside it");
+      if (wv & 1) {
+        double2* z = reinterpret_cast<double2*>(wv == 1 ? &sh.a.re[kMfdBand0][0] : &sh.a.im[kMfdBand0][0]);
+        for (int i = lane; i < (kFbBands - kMfdBand0) * kACols / 2; i += 64) z[i] = make_double2(0., 0.);
+      }
       FB_MARK(13);
       __syncthreads();                                               // every wave is done with its staging rows
 #pragma unroll
@@ -1170,11 +1180,6 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
           sh.a.re[2 * (wv + 4 * q) + sub][lane] = lane < kTileSub ? yr[q][sub] : 0.;
           sh.a.im[2 * (wv + 4 * q) + sub][lane] = lane < kTileSub ? yi[q][sub] : 0.;
         }
-      for (int i = tid; i < (kFbBands - kMfdBand0) * kACols; i += 256) {
-        (&sh.a.re[kMfdBand0][0])[i] = 0.;
-        (&sh.a.im[kMfdBand0][0])[i] = 0.;
-      }
-      __syncthreads();
       FB_MARK(14);
       fir_mfma_tail<M>(sh, reinterpret_cast<const WT*>(fb->mfd_re), reinterpret_cast<const WT*>(fb->mfd_im), wv, lane);
     } else if constexpr (sizeof(WT) == 4)
