@@ -184,8 +184,8 @@ class Context:
         return {k: getattr(st, k) for k, _ in Settings._fields_}
 
     def set_fir_fp64(self, enable):
-        """advanced version: every stage FP64, FIR bank on the FP64 matrix instruction (False: back to the default,
-        the split-FP16 FIR; see include/peaq_amd.h PEAQ_FIR_*)"""
+        """advanced version: True = every stage FP64, FIR bank on the FP64 matrix instruction (the engine's default);
+        False = the opt-in split-FP16 FIR (see include/peaq_amd.h PEAQ_FIR_*)"""
         _check(self.L.peaq_ctx_set_fir_fp64(self.h, int(bool(enable))))
 
     def set_fir_mode(self, mode):

@@ -17,9 +17,9 @@
  * that `audioresample` (resample_to_48k below).  Against the real reference
  * chain ODG/DI agree to 6e-5 in seven of eight pinned cases and 2.3e-3 in the
  * eighth (tests/test_cli_resampler.py; stated tolerance 5e-3).  48 kHz files:
- * digit for digit in both versions -- this tool runs the advanced version's
- * filter bank in FP64 like the reference; PEAQ_AMD_FIR=f16x3 selects the
- * engine's reduced-precision bank (held to 1e-6 in ODG/DI, include/peaq_amd.h).
+ * digit for digit in both versions -- the advanced version's filter bank runs
+ * in FP64 like the reference (the engine's default); PEAQ_AMD_FIR=f16x3 selects
+ * the reduced-precision bank (held to 1e-6 in ODG/DI, include/peaq_amd.h).
  * --no-resample refuses files at other rates instead.
  */
 #include <math.h>
@@ -341,13 +341,8 @@ main (int argc, char **argv)
     printf ("Error: peaq engine could not be instantiated - %s\n", peaq_last_error ());
     return 2;
   }
-  /* One file pair is not a throughput job: the advanced version's filter bank runs in the reference's own
-   * arithmetic (all FP64) here, the engine's faster reduced-precision bank only on request (PEAQ_AMD_FIR). */
-  if (advanced && !getenv ("PEAQ_AMD_FIR") && !getenv ("PEAQ_AMD_FIR_FP64")
-      && peaq_ctx_set_fir_mode (ctx, PEAQ_FIR_F64) != PEAQ_OK) {
-    printf ("Error: %s\n", peaq_last_error ());
-    return 2;
-  }
+  /* The advanced version's filter bank runs in the engine's default arithmetic, the reference's own (all FP64);
+   * the faster reduced-precision bank only on request (PEAQ_AMD_FIR=f16x3, read by peaq_ctx_create). */
   if (!getenv ("PEAQ_AMD_CLI_STREAM")) {
     /* both files are in memory: one call, every kernel sees the whole stream (a 5-minute pair of the advanced
      * version: 2 s instead of the 4 s of buffer-by-buffer sessions) */

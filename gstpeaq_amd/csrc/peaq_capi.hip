@@ -68,7 +68,7 @@ static int fail(int code, const std::string& msg) {
   } while (0)
 
 extern "C" const char* peaq_last_error(void) { return g_err.c_str(); }
-extern "C" const char* peaq_version(void) { return "0.1.0 gfx950"; }
+extern "C" const char* peaq_version(void) { return "0.2.0 gfx950 (advanced version: FP64 filter bank by default; f16x3 and f32 opt-in)"; }
 // host only, no device: the filter-bank tables of the FP64 engine against the reference's plain sums (peaq_tables.cpp)
 extern "C" double peaq_debug_fb_tables_selfcheck(void) { return peaq::fb_tables_selfcheck(); }
 
@@ -145,7 +145,7 @@ struct peaq_ctx {
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
   unsigned long long* d_prof = nullptr;   // -DPEAQ_FE_PROFILE builds only
-  int fir_fp64 = 2;                       // advanced version: arithmetic of the FIR bank (PEAQ_FIR_*; default the split-FP16 form)
+  int fir_fp64 = 1;                       // advanced version: arithmetic of the FIR bank (PEAQ_FIR_*; default the reference's FP64)
   Settings settings;                      // the reference's settings.h switches (peaq_ctx_set_settings)
 
   hipEvent_t next_event() {
@@ -171,8 +171,8 @@ extern "C" int peaq_ctx_create(int device, peaq_ctx** out) {
   if (!c) return fail(PEAQ_ERR_NOMEM, "out of host memory");
   c->device = device;
   {
-    const char* e = std::getenv("PEAQ_AMD_FIR_FP64");
-    if (e && *e && *e != '0') c->fir_fp64 = 1;
+    const char* e = std::getenv("PEAQ_AMD_FIR_FP64");    // "0": the reduced-precision engine, anything else: FP64 (the default)
+    if (e && *e) c->fir_fp64 = *e != '0' ? 1 : 2;
     if (const char* m = std::getenv("PEAQ_AMD_FIR")) {     // "f16x3" | "f32" | "f64"
       const std::string mode(m);
       if (mode == "f64") c->fir_fp64 = 1;
@@ -311,7 +311,7 @@ extern "C" int peaq_ctx_device(const peaq_ctx* c) { return c ? c->device : -1; }
 extern "C" int peaq_ctx_set_fir_fp64(peaq_ctx* c, int enable) {
   if (!c) return fail(PEAQ_ERR_ARG, "peaq_ctx_set_fir_fp64: ctx is NULL");
   std::lock_guard<std::mutex> lock(c->mu);
-  c->fir_fp64 = enable ? 1 : 2;                      // off = back to the default (PEAQ_FIR_F16X3)
+  c->fir_fp64 = enable ? 1 : 2;                      // off = the reduced-precision engine (PEAQ_FIR_F16X3)
   return PEAQ_OK;
 }
 extern "C" int peaq_ctx_get_fir_fp64(const peaq_ctx* c) { return c ? c->fir_fp64 == 1 : -1; }

@@ -84,9 +84,12 @@ enum : int {
   kDppHalfMirror = 0x141,  // lane i <- lane 7 - i of its group of 8 (all lanes of a quad agree by then)
   kDppMirror = 0x140       // lane i <- lane 15 - i of its row of 16
 };
+// (bound_ctrl set: with every row and bank enabled the compiler then knows the destination's old value is never
+// kept and does not zero it first -- two moves and a wait state per double saved; in these patterns every lane
+// has a source, so the "0 for lanes without one" never shows)
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v) {
@@ -319,6 +322,12 @@ template <long long BITS> __device__ __forceinline__ double scalar_const() {
   return __hiloint2double((int)hi, (int)lo);
 }
 #define PEAQ_KC(c) (SK ? scalar_const<__builtin_bit_cast(long long, (double)(c))>() : (double)(c))
+__device__ __forceinline__ double fma_sgpr(double a, double b, double c_scalar) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_scalar));
+  return r;
+}
+#define PEAQ_SC(c) scalar_const<__builtin_bit_cast(long long, (double)(c))>()
 // a * b + c with c such a scalar constant: written out because the compiler would select the two-address v_fmac_f64
 // here and pay two v_mov_b32 per Horner step to move the constant into the accumulator first
 template <bool SK, long long BITS> __device__ __forceinline__ double fma_const(double a, double b) {
@@ -335,7 +344,7 @@ template <bool SK, long long BITS> __device__ __forceinline__ double fma_const(d
 // ln x for finite x > 0 (subnormals included).  x = m 2^e with m in [sqrt(1/2), sqrt(2));
 // ln m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716: odd series up to s^19 (truncation
 // < 2e-17 relative); e ln 2 is added as a 32-bit high part (exact product) plus a low part.
-template <bool SK = false> __device__ __forceinline__ double log_pos(double x) {
+template <bool SK = true> __device__ __forceinline__ double log_pos(double x) {
   double m = __builtin_amdgcn_frexp_mant(x);         // [0.5, 1)
   int e = __builtin_amdgcn_frexp_exp(x);
   const bool low = m < PEAQ_KC(0.70710678118654752440);
@@ -381,13 +390,12 @@ __device__ __forceinline__ double log_tab(double x, const double* __restrict__ t
   const double2 t = *reinterpret_cast<const double2*>(tab + 2 * idx);
   e -= idx < (unsigned)kLogTabFold ? 1 : 0;
   const double r = fma(m, t.x, -1.);
-  double p = -1. / 6;
-  p = fma(p, r, 1. / 5);
-  p = fma(p, r, -1. / 4);
-  p = fma(p, r, 1. / 3);
+  double p = fma_sgpr(PEAQ_SC(-1. / 6), r, PEAQ_SC(1. / 5));   // (the constants in scalar registers: fma_sgpr)
+  p = fma_sgpr(p, r, PEAQ_SC(-1. / 4));
+  p = fma_sgpr(p, r, PEAQ_SC(1. / 3));
   p = fma(p, r, -0.5);
   const double l1p = fma(r * r, p, r);
-  return fma((double)e, 6.93147180559945286227e-01, t.y) + l1p;
+  return fma((double)e, PEAQ_SC(6.93147180559945286227e-01), t.y) + l1p;
 }
 #ifdef PEAQ_NO_LOGTAB_FE
 #define FE_LOG(x, tab) log_pos(x)
@@ -404,14 +412,14 @@ __device__ __forceinline__ double log_tab_nonneg(double x, const double* __restr
 
 // the same for any x >= 0 or NaN: ln 0 = -inf, ln inf = inf (digital silence reaches the
 // logarithms of the error-harmonic-structure and of the filter-bank slope computation)
-template <bool SK = false> __device__ __forceinline__ double log_nonneg(double x) {
+template <bool SK = true> __device__ __forceinline__ double log_nonneg(double x) {
   const double l = log_pos<SK>(x);
   return x == 0. ? -__builtin_inf() : (x == __builtin_inf() ? __builtin_inf() : l);
 }
 
 // e^x for any finite x or -inf (underflows to 0, overflows to inf through ldexp).
 // x = n ln 2 + r, |r| <= 0.3466; e^r as its Taylor polynomial of degree 12 (truncation 1.7e-16).
-template <bool SK = false> __device__ __forceinline__ double exp_fast(double x) {
+template <bool SK = true> __device__ __forceinline__ double exp_fast(double x) {
   x = fmin(fmax(x, -1000.), 1000.);
   const double n = __builtin_rint(x * PEAQ_KC(1.44269504088896338700e+00));
   double r = fma(-n, PEAQ_KC(6.93147180369123816490e-01), x);
@@ -437,12 +445,6 @@ template <bool SK = false> __device__ __forceinline__ double exp_fast(double x) 
 // exp_fast<true> on each element, so the results are theirs bit for bit; what changes is that a constant is
 // set up once per Horner step rather than once per step AND element (two s_mov_b32 each, and a wave issues
 // scalar and vector instructions in order), and that the N chains are independent of each other.
-__device__ __forceinline__ double fma_sgpr(double a, double b, double c_scalar) {
-  double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_scalar));
-  return r;
-}
-#define PEAQ_SC(c) scalar_const<__builtin_bit_cast(long long, (double)(c))>()
 template <int N> __device__ __forceinline__ void log_nonneg_n(double (&x)[N]) {
   double s[N], z[N], p[N], ef[N];
   const double rt = PEAQ_SC(0.70710678118654752440);

@@ -25,7 +25,7 @@
 #define PACKAGE "gstpeaq-amd"
 #endif
 #ifndef PACKAGE_VERSION
-#define PACKAGE_VERSION "0.1.0"
+#define PACKAGE_VERSION "0.2.0"
 #endif
 
 GST_DEBUG_CATEGORY_STATIC (peaq_amd_debug);
@@ -83,13 +83,9 @@ shared_context (void)
       GST_ERROR ("libpeaq_amd: %s", peaq_last_error ());
       ctx = NULL;
     } else {
-      /* A pipeline with its own session per element is not a throughput job: the advanced version's filter
-       * bank runs in the reference's arithmetic (all FP64).  A process that batches its elements through the
-       * broker keeps the engine's default, the faster reduced-precision bank; PEAQ_AMD_FIR overrides both. */
-      const gchar *max = g_getenv ("PEAQ_AMD_BROKER");
-      if (!(max && atoi (max) > 0) && !g_getenv ("PEAQ_AMD_FIR") && !g_getenv ("PEAQ_AMD_FIR_FP64")
-          && peaq_ctx_set_fir_mode (ctx, PEAQ_FIR_F64) != PEAQ_OK)
-        GST_WARNING ("libpeaq_amd: %s", peaq_last_error ());
+      /* The advanced version's filter bank runs in the engine's default arithmetic, the reference's own (all
+       * FP64), whether the elements keep their own sessions or share a broker; PEAQ_AMD_FIR=f16x3 in the
+       * environment selects the faster reduced-precision bank (peaq_ctx_create reads it). */
       /* decided once per process, when the first element is created: say which it was */
       GST_INFO ("libpeaq_amd: device %d, filter-bank arithmetic of the advanced version: %s", peaq_ctx_device (ctx),
                 peaq_ctx_get_fir_mode (ctx) == PEAQ_FIR_F64 ? "f64" : peaq_ctx_get_fir_mode (ctx) == PEAQ_FIR_F32 ? "f32" : "f16x3");

@@ -90,21 +90,25 @@ int peaq_ctx_get_settings (const peaq_ctx *ctx, peaq_settings *s);
 
 /* Advanced version only: the arithmetic of the filter-bank ear model's front half
  * (fbearmodel.c:327-435: the 40 complex FIR filters, the level-dependent slopes, the upward spreading).
- *   PEAQ_FIR_F16X3 (default): the FIR bank on v_mfma_f32_16x16x32_f16 with signal and coefficients split
- *       into a high and a low FP16 part and three products per term (about 22 bits), FP32 accumulation;
- *       slopes and upward spreading in FP32, the slope filter (the one recurrence along the stream) FP64.
- *       Tolerances this mode is held to by the parity suite (tests/gpu_common.py): MOVs 2e-6 relative, DI and
- *       ODG 1e-6 against the real reference's goldens; per-block excitation 1e-4; a stream cut into launches
- *       in different ways (session, broker, batch) agrees with itself to 1e-9.  Measured max |dODG| against
- *       the all-FP64 path: 5e-7 over 39 advanced cases (profiles/r02_precision_ledger.json), 6e-6 over 4096
- *       ten-second pairs (bench.py, advanced.reduced_precision_default).  No range limit: a signal whose
- *       filtered peak leaves the FP16 headroom (30 dB above full scale) runs at its own power-of-two scale.
- *   PEAQ_FIR_F32: the FIR bank on v_mfma_f32_16x16x4_f32 (5e-8), everything after it FP64.
- *   PEAQ_FIR_F64: v_mfma_f64_16x16x4_f64, follows the reference's double arithmetic to 1e-9 per block;
- *       peaq_ctx_set_fir_fp64(ctx, 1) and the environment variable PEAQ_AMD_FIR_FP64=1 select it too
- *       (peaq_ctx_set_fir_fp64(ctx, 0) returns to the default).
- * PEAQ_AMD_FIR=f16x3|f32|f64 in the environment sets the mode at context creation.  The basic version and
- * everything downstream of the spreading are FP64 in every mode.  Applies to the launches that follow. */
+ *   PEAQ_FIR_F64 (default): the reference's double arithmetic -- v_mfma_f64_16x16x4_f64 and FP64 vector
+ *       instructions throughout; follows the oracle to 1e-9 per block (tests/gpu_common.py, column "default").
+ *       Bands 0..23 are evaluated in the block-sum form of DESIGN.md section 10 (a third of the reference's
+ *       multiply-adds), bands 24..39 as plain sums.
+ *   PEAQ_FIR_F16X3 (opt-in, 1.5x the throughput of the default on MI355X): the FIR bank on
+ *       v_mfma_f32_16x16x32_f16 with signal and coefficients split into a high and a low FP16 part and three
+ *       products per term (about 22 bits), FP32 accumulation; slopes and upward spreading in FP32, the slope
+ *       filter (the one recurrence along the stream) FP64.  Tolerances this mode is held to by the parity suite
+ *       (tests/gpu_common.py, column "f16x3"): MOVs 2e-6 relative, DI and ODG 1e-6 against the real reference's
+ *       goldens; per-block excitation 1e-4; a stream cut into launches in different ways (session, broker,
+ *       batch) agrees with itself to 1e-9.  Measured max |dODG| against the FP64 engine: 5e-7 over 39 advanced
+ *       cases (profiles/r02_precision_ledger.json), 6e-6 over 4096 ten-second pairs (bench.py,
+ *       advanced.reduced_precision_f16x3).  No range limit: a signal whose filtered peak leaves the FP16
+ *       headroom (30 dB above full scale) runs at its own power-of-two scale.
+ *   PEAQ_FIR_F32 (opt-in): the FIR bank on v_mfma_f32_16x16x4_f32 (5e-8), everything after it FP64.
+ * peaq_ctx_set_fir_fp64(ctx, 0) selects PEAQ_FIR_F16X3, (ctx, 1) PEAQ_FIR_F64; the environment variables
+ * PEAQ_AMD_FIR=f64|f16x3|f32 and PEAQ_AMD_FIR_FP64=1|0 set the mode at context creation.  peaq_version() names
+ * the default.  Until release 0.2.0 the default was PEAQ_FIR_F16X3.  The basic version and everything
+ * downstream of the spreading are FP64 in every mode.  Applies to the launches that follow. */
 #define PEAQ_FIR_F32   0
 #define PEAQ_FIR_F64   1
 #define PEAQ_FIR_F16X3 2

@@ -6,20 +6,20 @@ import numpy as np
 
 GOLD = Path(__file__).resolve().parent / "golden"
 
-# The advanced version's filter bank has two arithmetics (include/peaq_amd.h, peaq_ctx_set_fir_mode):
-#   "default"  what ships: FIR bank on the FP16 matrix instruction with split operands, slopes and upward
-#              spreading in FP32 (PEAQ_FIR_F16X3);
-#   "f64"      everything FP64 like the reference (PEAQ_FIR_F64).
+# The advanced version's filter bank has two arithmetics the suite runs (include/peaq_amd.h, peaq_ctx_set_fir_mode):
+#   "default"  what ships: everything FP64 like the reference (PEAQ_FIR_F64);
+#   "f16x3"    the opt-in fast engine: FIR bank on the FP16 matrix instruction with split operands, slopes and
+#              upward spreading in FP32 (PEAQ_FIR_F16X3).
 # Tests that take the `fir_mode` fixture (tests/conftest.py) run once per mode; every other test runs on the
 # default engine.  Tolerances of advanced-version results per mode, stated HERE and nowhere looser -- results of
-# the basic version never pass through the filter bank and are held to the "f64" column in either mode:
+# the basic version never pass through the filter bank and are held to the "default" column in either mode:
 #   movs    MOVs against the real reference's goldens / the oracle (relative; + 1e-9 absolute)
 #   odg     DI and ODG against the same (absolute; north star: 0.02)
 #   blocks  per-block excitation patterns of the filter bank against the oracle (relative)
 #   chunks  one stream cut into launches in different ways (session, broker, batch) against itself (relative)
-MODES = ("default", "f64")
-TOL = {"default": dict(movs=2e-6, odg=1e-6, blocks=1e-4, chunks=1e-9),
-       "f64": dict(movs=1e-7, odg=1e-7, blocks=1e-9, chunks=1e-10)}
+MODES = ("default", "f16x3")
+TOL = {"f16x3": dict(movs=2e-6, odg=1e-6, blocks=1e-4, chunks=1e-9),
+       "default": dict(movs=1e-7, odg=1e-7, blocks=1e-9, chunks=1e-10)}
 _MODE = "default"
 _CTX = {}
 
@@ -35,18 +35,20 @@ def mode():
 
 
 def tol(kind, advanced=True):
-    return TOL[_MODE if advanced else "f64"][kind]
+    return TOL[_MODE if advanced else "default"][kind]
 
 
 def ctx(mode=None):
     """The shared context of the parity tests in the current FIR mode (or the one asked for)."""
     m = mode or _MODE
+    if m == "f64":                                   # the default by its own name
+        m = "default"
     if m not in _CTX:
         import gstpeaq_amd
         c = gstpeaq_amd.Context(0)
-        assert c.fir_mode() == "f16x3", "the split-FP16 FIR must be the engine's default"
-        if m == "f64":
-            c.set_fir_fp64(True)
+        assert c.fir_mode() == "f64" and c.fir_fp64() is True, "the reference's FP64 arithmetic must be the engine's default"
+        if m == "f16x3":
+            c.set_fir_mode("f16x3")
         _CTX[m] = c
     return _CTX[m]
 

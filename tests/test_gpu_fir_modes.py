@@ -29,8 +29,9 @@ def fp32_ctx(request):
         pytest.fail("-m gpu tests need a GPU (there is no CPU fallback in the product)")
     import gstpeaq_amd
     c = gstpeaq_amd.Context(0)
-    assert c.fir_mode() == "f16x3" and c.fir_fp64() is False, "the split-FP16 FIR must be the default"
+    assert c.fir_mode() == "f64" and c.fir_fp64() is True, "the reference's FP64 arithmetic must be the default"
     c.set_fir_mode(request.param)
+    assert c.fir_mode() == request.param and c.fir_fp64() is False
     yield c
     c.close()
 
@@ -97,7 +98,7 @@ def test_fullsize_pairs_fp32_vs_fp64_fir(fp32_ctx):
 
 def test_samples_far_beyond_full_scale_are_scaled_not_saturated():
     """Float input far beyond full scale (the WAV float formats allow it; the reference's filter bank is FP64 and
-    has no range limit, fbearmodel.c:276-435): the FP16 operands of the default FIR hold 30 dB of headroom above
+    has no range limit, fbearmodel.c:276-435): the FP16 operands of the split-FP16 FIR hold 30 dB of headroom above
     full scale at the launch's scale; a signal whose filtered peak -- recorded by the high-pass walk -- goes beyond
     it runs at its own power of two instead (peaq_fb.hip, fb_bank_body).  +26 dB (inside the headroom), +60 dB
     and +100 dB all follow the FP64 engine to 1e-6 in ODG and 2e-6 in the MOVs; a burst far beyond full scale
@@ -106,6 +107,7 @@ def test_samples_far_beyond_full_scale_are_scaled_not_saturated():
     import gstpeaq_amd
     import gpu_common
     c = gstpeaq_amd.Context(0)
+    c.set_fir_fp64(False)                            # = PEAQ_FIR_F16X3
     assert c.fir_mode() == "f16x3"
     ref, test = case_defs.make_inputs(dict(kind="synth", seed=3, channels=2, n=48000))
     cases = [(ref * np.float32(g), test * np.float32(g)) for g in (20.0, 1000.0, 1e5)]

@@ -8,12 +8,12 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_fetch -o r -- py
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_write -o r -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-advanced --no-scaling-reference > $O/prof_write.log 2>&1
 python $R/tools/rocprof_summary.py pmc /tmp/p_fetch/r_results.db /tmp/p_write/r_results.db > $O/pmc_hbm_basic.json
 bash $R/tools/pmc_mix.sh
-# advanced, FP64 engine (configs[2] headline): statistics, timeline of one pass, counters of the bank kernel
+# advanced, the default FP64 engine (configs[2] headline): statistics, timeline of one pass, counters of the bank kernel
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_adv -o r -- python $R/bench.py --advanced --steps 1 --warmup 1 --no-cpu-baseline --no-scaling-reference > $O/prof_adv.log 2>&1
 python $R/tools/rocprof_summary.py stats /tmp/p_adv/r_results.db > $O/stats_adv.json
 python $R/tools/rocprof_summary.py timeline /tmp/p_adv/r_results.db 140 | grep "peaq::" | grep -v synth | tail -28 > $O/r04_timeline_adv.txt
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_advd -o r -- python $R/bench.py --advanced --reduced-precision --steps 1 --warmup 1 --no-cpu-baseline --no-scaling-reference > $O/prof_advd.log 2>&1
-python $R/tools/rocprof_summary.py stats /tmp/p_advd/r_results.db > $O/stats_adv_default.json
+python $R/tools/rocprof_summary.py stats /tmp/p_advd/r_results.db > $O/stats_adv_f16x3.json
 bash $R/tools/pmc_fb.sh
 cd $R
 if [ -f gstpeaq_amd/libpeaq_amd_fbprof.so ]; then
@@ -27,5 +27,5 @@ if [ -f gstpeaq_amd/libpeaq_amd_serial.so ]; then
 fi
 python bench.py > $O/bench_basic.json 2> $O/bench_basic.err
 python bench.py --advanced --steps 3 > $O/bench_adv.json 2> /dev/null
-python bench.py --advanced --reduced-precision --steps 3 > $O/bench_adv_default.json 2> /dev/null
+python bench.py --advanced --reduced-precision --steps 3 > $O/bench_adv_f16x3.json 2> /dev/null
 ls -la $O | tail -30

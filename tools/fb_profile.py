@@ -17,12 +17,11 @@ PHASES = ["0 window + zero A + barrier", "1 FIR (own run of K steps)", "2 barrie
           "4 shift window, request next", "5 log/exp/slope scan (10 bands)", "6 upward spreading", "7 barrier",
           "8 downward spreading + barrier", "9 backward masking + barrier", "10 history + barrier",
           "11 forward masking + barrier", "12 records",
-          "13 FP64 engine: block-sum form of bands 0..23 (inside 1)", "14 FP64 engine: barrier, results -> A, barrier (inside 1)"]
+          "13 FP64 engine: block-sum form of bands 0..23 (inside 1)", "14 FP64 engine: barrier, results -> A (inside 1)"]
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-MODE = sys.argv[2] if len(sys.argv) > 2 else None      # "f64": the FP64 engine
+MODE = sys.argv[2] if len(sys.argv) > 2 else "f64"     # "f64" (the engine's default) | "f16x3" | "f32"
 ctx = gstpeaq_amd.Context(0)
-if MODE == "f64":
-    ctx.set_fir_fp64(True)
+ctx.set_fir_mode(MODE)
 ref, test = gstpeaq_amd.synth_fill(ctx, 1, pairs, 2, 480000)
 buf = (C.c_ulonglong * 68)()
 ctx.L.peaq_debug_fb_profile.argtypes = [C.POINTER(C.c_ulonglong)]
@@ -30,7 +29,7 @@ gstpeaq_amd.batch_run(ctx, 1, ref, test)
 assert ctx.L.peaq_debug_fb_profile(buf) == 0
 gstpeaq_amd.batch_run(ctx, 1, ref, test)
 assert ctx.L.peaq_debug_fb_profile(buf) == 0
-out = {"fir_fp64": ctx.fir_fp64()}
+out = {"fir_mode": ctx.fir_mode(), "fir_fp64": ctx.fir_fp64()}
 for wv in range(4):
     n = buf[64 + wv]
     tot = sum(buf[wv * 16 + i] for i in range(16))
