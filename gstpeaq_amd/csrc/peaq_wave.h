@@ -315,6 +315,9 @@ __device__ __forceinline__ int wave_or_i(int v) {
 // A double constant placed in a scalar register pair by two s_mov_b32.  The filter bank's FP64 kernel is at its
 // register budget: there the compiler kept these polynomial coefficients in vector registers across the tile loop
 // and spilled them to scratch; scalar copies cost no vector register and at worst a v_readlane to bring back.
+#ifndef PEAQ_SK_DEFAULT
+#define PEAQ_SK_DEFAULT false      // (measured on the basic version: scalar constants everywhere cost 3 % -- the
+#endif                             // extra scalar instructions weigh more than the vector moves they replace)
 template <long long BITS> __device__ __forceinline__ double scalar_const() {
   unsigned lo, hi;
   asm("s_mov_b32 %0, %1" : "=s"(lo) : "i"((unsigned)(BITS & 0xffffffffll)));
@@ -344,7 +347,7 @@ template <bool SK, long long BITS> __device__ __forceinline__ double fma_const(d
 // ln x for finite x > 0 (subnormals included).  x = m 2^e with m in [sqrt(1/2), sqrt(2));
 // ln m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716: odd series up to s^19 (truncation
 // < 2e-17 relative); e ln 2 is added as a 32-bit high part (exact product) plus a low part.
-template <bool SK = true> __device__ __forceinline__ double log_pos(double x) {
+template <bool SK = PEAQ_SK_DEFAULT> __device__ __forceinline__ double log_pos(double x) {
   double m = __builtin_amdgcn_frexp_mant(x);         // [0.5, 1)
   int e = __builtin_amdgcn_frexp_exp(x);
   const bool low = m < PEAQ_KC(0.70710678118654752440);
@@ -390,12 +393,14 @@ __device__ __forceinline__ double log_tab(double x, const double* __restrict__ t
   const double2 t = *reinterpret_cast<const double2*>(tab + 2 * idx);
   e -= idx < (unsigned)kLogTabFold ? 1 : 0;
   const double r = fma(m, t.x, -1.);
-  double p = fma_sgpr(PEAQ_SC(-1. / 6), r, PEAQ_SC(1. / 5));   // (the constants in scalar registers: fma_sgpr)
-  p = fma_sgpr(p, r, PEAQ_SC(-1. / 4));
-  p = fma_sgpr(p, r, PEAQ_SC(1. / 3));
+  constexpr bool SK = PEAQ_SK_DEFAULT;
+  double p = -1. / 6;
+  p = PEAQ_FMA_KC(p, r, 1. / 5);
+  p = PEAQ_FMA_KC(p, r, -1. / 4);
+  p = PEAQ_FMA_KC(p, r, 1. / 3);
   p = fma(p, r, -0.5);
   const double l1p = fma(r * r, p, r);
-  return fma((double)e, PEAQ_SC(6.93147180559945286227e-01), t.y) + l1p;
+  return fma((double)e, PEAQ_KC(6.93147180559945286227e-01), t.y) + l1p;
 }
 #ifdef PEAQ_NO_LOGTAB_FE
 #define FE_LOG(x, tab) log_pos(x)
@@ -412,14 +417,14 @@ __device__ __forceinline__ double log_tab_nonneg(double x, const double* __restr
 
 // the same for any x >= 0 or NaN: ln 0 = -inf, ln inf = inf (digital silence reaches the
 // logarithms of the error-harmonic-structure and of the filter-bank slope computation)
-template <bool SK = true> __device__ __forceinline__ double log_nonneg(double x) {
+template <bool SK = PEAQ_SK_DEFAULT> __device__ __forceinline__ double log_nonneg(double x) {
   const double l = log_pos<SK>(x);
   return x == 0. ? -__builtin_inf() : (x == __builtin_inf() ? __builtin_inf() : l);
 }
 
 // e^x for any finite x or -inf (underflows to 0, overflows to inf through ldexp).
 // x = n ln 2 + r, |r| <= 0.3466; e^r as its Taylor polynomial of degree 12 (truncation 1.7e-16).
-template <bool SK = true> __device__ __forceinline__ double exp_fast(double x) {
+template <bool SK = PEAQ_SK_DEFAULT> __device__ __forceinline__ double exp_fast(double x) {
   x = fmin(fmax(x, -1000.), 1000.);
   const double n = __builtin_rint(x * PEAQ_KC(1.44269504088896338700e+00));
   double r = fma(-n, PEAQ_KC(6.93147180369123816490e-01), x);
