@@ -63,7 +63,17 @@ enum { HF_RE_HI_1, HF_RE_LO_1, HF_IM_HI_1, HF_IM_LO_1, HF_RE_HI_2, HF_RE_LO_2, H
 constexpr int kBsBands  = 24;
 constexpr int kBsPairs  = kBsBands / 2;
 constexpr int kBsChains = kBsBands * 3;
-constexpr int kBsHist   = 44;     // the longest filter's whole blocks
+constexpr int kBsHistOrg = 8;     // a history row starts with eight zeros (outputs in front of a window's first whole block)
+constexpr int kBsHist   = kBsHistOrg + 44;   // ... followed by up to 44 enter values: the longest filter's whole blocks
+// Rows of a pair's 16-row tile: the enter rows first (re of the six chains -- chain = 3 * band-in-pair + exponential --,
+// then im), then the rows of the block the windows end in (re of both bands, im of both bands).  ty as in the
+// tables' construction: 2 * exponential + {re, im} for ty < 6, 6 / 7 = re / im of the end block.
+constexpr int bs_row(int sub, int ty) { return ty < 6 ? (ty & 1) * 6 + 3 * sub + (ty >> 1) : 12 + 2 * (ty - 6) + sub; }
+// The running sums are evaluated with a lane per (chain, segment of kBsSeg consecutive outputs): eight segments per
+// chain, shifted so that output J = bs_whole[band] starts a segment (the segments in front of it take the values that
+// leave from the history, the others from this tile) -- s = bs_seg_s[band] outputs of the first segment lie in front
+// of output 0 and read zeros.
+constexpr int kBsSeg = 9;
 // the direct tile: bands 24 .. 39, delays kMfdD0 .. 729 in kMfdSteps K steps of four
 constexpr int kMfdBand0 = 24;
 constexpr int kMfdD0    = 611;
@@ -160,6 +170,11 @@ struct FbTables {               // fbearmodel.c:57-61,182-225
   double bs_left[kBsBands][32][2];      // the filter's own coefficients (re, im) on the block the window starts in
   double bs_rot[kBsChains][2][2];       // chain = 3 band + i: rot = e^(j 32 w_i) and rot^J (re, im)
   double bs_pow[kBsChains][64][2];      // rot^(l + 1), l = 0..63
+  int    bs_seg_s[kBsBands];            // (kBsSeg - J % kBsSeg) % kBsSeg
+  // per pair and lane (chain c = min(lane >> 3, 5) of the pair, segment g = lane & 7), complex:
+  //   [0..2] rot^(kBsSeg 2^l), l = 0..2, the weights of the scan over a chain's segments (0 where g < 2^l)
+  //   [3] rot^(kBsSeg g - s)   [4] rot   [5] rot^J
+  double bs_seg[kBsPairs][6][64][2];
   double mfd_re[kMfdSteps * 64];        // the direct tile's A operands, lane = band - 24 + 16 (d - kMfdD0 - 4 s)
   double mfd_im[kMfdSteps * 64];
 };
@@ -287,7 +302,8 @@ struct FbSignalState {
   double peak_slot[3][2];
   double peak_last;
   // FP64 engine, block-sum form of the long filters (kBs*): per band and exponential the last J = bs_whole[band]
-  // enter values (re, im), oldest first -- what the direct form's delay line is to the samples
+  // enter values (re, im), oldest first, behind kBsHistOrg zeros that are never written -- what the direct form's
+  // delay line is to the samples
   double bs_hist[kBsBands][6][kBsHist];
 };
 

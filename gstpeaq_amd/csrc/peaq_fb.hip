@@ -528,9 +528,11 @@ __device__ __forceinline__ void fir_mfma_tail(BankLds<typename M::T>& sh, const 
 // ---------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) double kdouble;   // read through the scalar cache when the address is uniform
 typedef const __attribute__((address_space(4))) int kint;
-constexpr int kStRow = 80;                           // staging row stride in doubles (= 16 mod 32: four rows, two bank halves)
+constexpr int kStRow = 72;                           // staging row stride in doubles: eight front slots + 64 outputs (= 8 mod 32: the rows of
+                                                     // the four chains of a half wave start on four different bank groups)
 constexpr int kStOrg = 8;                            // index of output 0 in a row (entries in front: outputs < 0 of the shifted rows)
-constexpr int kStWave = 16 * kStRow;                 // doubles per wave
+constexpr int kStWave = 1280;                        // doubles per wave (16 rows + the last row's reads beyond output 63)
+static_assert(16 * kStRow + 16 <= kStWave, "rows + overhang");
 static_assert(4 * kStWave <= 2 * kFbBands * kACols, "the staging rows of the four waves live where A will be");
 
 // the A operands of a pair's tile (eight K steps): requested a pair ahead of their use
@@ -617,6 +619,7 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
                                         double* __restrict__ lcoef, const FbTables* __restrict__ fb, double* __restrict__ hist,
                                         int p, bool first_tile, int nvs, int lane, double (&a)[8], double (&yr)[2],
                                         double (&yi)[2]) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
   const int j = lane & 15, kk = lane >> 4;
   // the tables' uniform entries travel through the scalar cache (constant address space)
   kint* t_head = (kint*)(const void*)fb->bs_col_head;
@@ -624,41 +627,53 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
   kint* t_left = (kint*)(const void*)fb->bs_col_left;
   kint* t_q0 = (kint*)(const void*)fb->bs_left_q0;
   kint* t_whole = (kint*)(const void*)fb->bs_whole;
+  kint* t_segs = (kint*)(const void*)fb->bs_seg_s;
   const int col_head = t_head[p];
-  // the history of the pair's twelve rows: lane i < J holds enter(i - J); requested first, used after the matrix work.
-  // Lanes from J on are never looked at (a prefix sum read at lane J - 1, a select on lane < J, a shuffle from
-  // lanes < J): they load whatever the clamped index finds -- twelve loads off one address, no branches.
-  double h[2][6];
+  const int J0 = t_whole[2 * p], J1 = t_whole[2 * p + 1];
+  // the lane's part in the running sums: chain c of the pair (3 * band + exponential; lanes 48 .. 63 repeat chain 5),
+  // segment g = outputs t0 .. t0 + 8
+  const int c = min(lane >> 3, 5), g = lane & 7;
+  const bool second = c >= 3;
+  const int Jl = second ? J1 : J0;
+  const int t0 = kBsSeg * g - (second ? t_segs[2 * p + 1] : t_segs[2 * p]);
+  const bool from_hist = t0 < Jl;                      // (output J starts a segment: all of this one leaves from the history)
+  // what leaves the sums at the lane's outputs if that is history: requested first, used after the matrix work (the
+  // other lanes read valid memory too and replace it below)
+  double lr[kBsSeg], li[kBsSeg];
+  {
+    const double* hp = hist + ((size_t)(2 * p + (second ? 1 : 0)) * 6 + 2 * (c - (second ? 3 : 0))) * kBsHist + kBsHistOrg +
+                       (from_hist ? t0 : 0);
+#pragma unroll
+    for (int k = 0; k < kBsSeg; ++k) {
+      lr[k] = hp[k];
+      li[k] = hp[kBsHist + k];
+    }
+  }
   double cl[2];                                        // the first blocks' coefficients (bs_left): 64 doubles per band
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) cl[sub] = (&fb->bs_left[2 * p + sub][0][0])[lane];
+  // the chain's constants (FbTables::bs_seg): scan weights, rot^(9 g - s), rot, rot^J
+  v2d w1, w2, w4, kp, rot, rj;
   {
-    const double* hrow = hist + (size_t)(2 * p) * 6 * kBsHist + min(lane, kBsHist - 1);
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-      for (int r = 0; r < 6; ++r) h[sub][r] = hrow[(sub * 6 + r) * kBsHist];
-      cl[sub] = (&fb->bs_left[2 * p + sub][0][0])[lane];
-    }
+    const v2d* sg = reinterpret_cast<const v2d*>(&fb->bs_seg[p][0][lane][0]);
+    w1 = sg[0];
+    w2 = sg[64];
+    w4 = sg[128];
+    kp = sg[192];
+    rot = sg[256];
+    rj = sg[320];
   }
-  // r^(lane + 1) of the six chains, and r^J through the scalar cache (constant address space): all in flight during
-  // the matrix work (requested where they are used, every chain waited for its own)
-  double pwr[6], pwi[6], rjr[6], rji[6];
-  {
-    kdouble* rk = (kdouble*)(const void*)&fb->bs_rot[6 * p][0][0];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const double2 v = *reinterpret_cast<const double2*>(fb->bs_pow[6 * p + c][lane]);
-      pwr[c] = v.x;
-      pwi[c] = v.y;
-      rjr[c] = rk[4 * c + 2];
-      rji[c] = rk[4 * c + 3];
-    }
-  }
-  // staging index of accumulator element i (row kk + 4 i: band i >> 1 of the pair, type kk + 4 (i & 1)) of column tile 0
+  // staging index of accumulator element i (row kk + 4 i of the tile, bs_row) of column tile 0: a row's entries sit at
+  // their OUTPUT's index (the rows of the second band and of the end blocks start some columns later)
   int ih[4];
+  {
+    const int off0 = t_off[2 * p], off1 = t_off[2 * p + 1];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ty = kk + 4 * (i & 1);
-    ih[i] = (kk + 4 * i) * kStRow + kStOrg + j - t_off[2 * p + (i >> 1)] - (ty >= 6 ? 1 : 0);
+    for (int i = 0; i < 4; ++i) {
+      const int row = kk + 4 * i;
+      const bool sb = i == 3 ? (row & 1) : (i == 0 ? row >= 3 : (i == 1 ? row < 6 : row >= 9));   // the row's band in the pair
+      ih[i] = row * kStRow + kStOrg + j - (sb ? off1 : off0) - (i == 3 ? 1 : 0);
+    }
   }
   {
     v4d acc[4];
@@ -669,16 +684,124 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
 #pragma unroll
       for (int i = 0; i < 4; ++i) stg[ih[i] + 16 * nt] = acc[nt][i];
   }
-  double z15 = 0., z31 = 0.;                           // the scans' row carries land in these (dpp_rows_keep)
+  // the eight slots in front of output 0 of the twelve enter rows read as zero (outputs in front of the first segment;
+  // the shifted rows of the tile have just put their columns -3 .. -1 there)
+  // -- of all sixteen rows: the last enter row's outputs 64 .. 71 are the first end-block row's front slots, and what
+  // a lane computes from them is multiplied by zero in its neighbour chain's scan: it has to be finite
+  stg[(lane >> 3) * kStRow + (lane & 7)] = 0.;
+  stg[(8 + (lane >> 3)) * kStRow + (lane & 7)] = 0.;
+  // ... and so have outputs 61 .. 63 (nobody's, but inside the last segment), which a row shifted by two or three
+  // columns does not get from the tile: they would be whatever phase of the previous tile used this part of A last
+  if (lane < 48) stg[(lane / 3) * kStRow + kStOrg + 61 + lane % 3] = 0.;
   lcoef[lane] = cl[0];                                 // the first blocks' coefficients where every lane can read them
   lcoef[64 + lane] = cl[1];
   wave_lds_fence();
+  if (first_tile) {
+    // a launch's first tile: V(-1) of the six chains from the history, lanes = history entries (one prefix scan each)
+    double z15 = 0., z31 = 0.;
+#pragma unroll 1
+    for (int c2 = 0; c2 < 6; ++c2) {
+      const int sub = c2 >= 3 ? 1 : 0, J = sub ? J1 : J0;
+      const double* hp = hist + ((size_t)(2 * p + sub) * 6 + 2 * (c2 - 3 * sub)) * kBsHist + kBsHistOrg + min(lane, kBsHist - kBsHistOrg - 1);
+      double ar = hp[0], ai = hp[kBsHist];
+      const double2 pw = *reinterpret_cast<const double2*>(fb->bs_pow[6 * p + c2][lane]);
+      bs_chain(ar, ai, 0., 0., pw.x, pw.y, lane, z15, z31);
+      const double v_r = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ar), J - 1),
+                                          __builtin_amdgcn_readlane(__double2loint(ar), J - 1));
+      const double v_i = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ai), J - 1),
+                                          __builtin_amdgcn_readlane(__double2loint(ai), J - 1));
+      if (lane == 0) {
+        vst[6 * p + c2][0] = v_r;
+        vst[6 * p + c2][1] = v_i;
+      }
+    }
+    wave_lds_fence();
+  }
+  // ---- the running sums, a lane per (chain, segment) -----------------------------------------------------------------
+  double* erow = stg + c * kStRow + kStOrg + t0;       // the chain's enter values (re; im six rows on) at the lane's outputs
+  if (!from_hist) {                                    // what leaves is this tile's: the entries J outputs back
+#pragma unroll
+    for (int k = 0; k < kBsSeg; ++k) {
+      lr[k] = erow[k - Jl];
+      li[k] = erow[6 * kStRow + k - Jl];
+    }
+  }
+  double dr[kBsSeg], di[kBsSeg];                       // enter(t) - rot^J enter(t - J)
+#pragma unroll
+  for (int k = 0; k < kBsSeg; ++k) {
+    dr[k] = fma(-rj.x, lr[k], fma(rj.y, li[k], erow[k]));
+    di[k] = fma(-rj.x, li[k], fma(-rj.y, lr[k], erow[6 * kStRow + k]));
+  }
+  // the history after this tile: lane i < J <- enter(nvs - J + i) -- before the sums take the rows' place
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub) {
-    const int b = 2 * p + sub, J = t_whole[b];
-    const double* urow = stg + 8 * sub * kStRow + kStOrg + lane;
-    // the block the window starts in: its samples inside the window (from q0 on) x the filter's own coefficients
-    double sr = urow[6 * kStRow], si = urow[7 * kStRow];     // ... on top of the block it ends in
+    const int b = 2 * p + sub, J = sub ? J1 : J0;
+    const int src = nvs - J + lane;
+    double hn[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) hn[r] = stg[bs_row(sub, r) * kStRow + kStOrg + max(src, 0)];
+    double* hrow = hist + (size_t)b * 6 * kBsHist + kBsHistOrg;
+    if (nvs < J) {                                     // a short tile (the last of a launch): part of the old history stays
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double old = hrow[r * kBsHist + min(lane + nvs, kBsHist - kBsHistOrg - 1)];
+        hn[r] = src >= 0 ? hn[r] : old;
+      }
+    }
+    if (lane < J) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) hrow[r * kBsHist + lane] = hn[r];
+    }
+  }
+  // the segment's sum with nothing carried in (Horner in rot), ...
+  double tr = dr[0], ti = di[0];
+#pragma unroll
+  for (int k = 1; k < kBsSeg; ++k) {
+    const double nr = fma(rot.x, tr, fma(-rot.y, ti, dr[k]));
+    ti = fma(rot.x, ti, fma(rot.y, tr, di[k]));
+    tr = nr;
+  }
+  // ... the scan over the chain's eight segments (weights rot^9, rot^18, rot^36; zero where the source would be another
+  // chain's lane) ...
+#define PEAQ_BS_SCAN(SH, W)                                          \
+  {                                                                  \
+    const double sr_ = dpp_d0<kDppRowShr + SH>(tr), si_ = dpp_d0<kDppRowShr + SH>(ti); \
+    tr = fma(W.x, sr_, fma(-W.y, si_, tr));                          \
+    ti = fma(W.x, si_, fma(W.y, sr_, ti));                           \
+  }
+  PEAQ_BS_SCAN(1, w1)
+  PEAQ_BS_SCAN(2, w2)
+  PEAQ_BS_SCAN(4, w4)
+#undef PEAQ_BS_SCAN
+  // ... what the lane starts from: the sums at the end of the segment in front of it, plus what V(-1) has become there
+  double vr, vi;
+  {
+    const double pr_ = dpp_d0<kDppRowShr + 1>(tr), pi_ = dpp_d0<kDppRowShr + 1>(ti);
+    const double m = g > 0 ? 1. : 0.;
+    const v2d v = *(const __attribute__((address_space(3))) v2d*)&vst[6 * p + c][0];
+    vr = fma(m, pr_, fma(kp.x, v.x, -kp.y * v.y));
+    vi = fma(m, pi_, fma(kp.x, v.y, kp.y * v.x));
+  }
+  // ... and the sums themselves, written over the enter values
+#pragma unroll
+  for (int k = 0; k < kBsSeg; ++k) {
+    const double nr = fma(rot.x, vr, fma(-rot.y, vi, dr[k]));
+    vi = fma(rot.x, vi, fma(rot.y, vr, di[k]));
+    vr = nr;
+    erow[k] = vr;
+    erow[6 * kStRow + k] = vi;
+  }
+  wave_lds_fence();                                    // (other lanes read the sums from here on)
+  if (lane < 6) {                                      // carried to the next tile: the sums at the last valid output
+    vst[6 * p + lane][0] = stg[lane * kStRow + kStOrg + nvs - 1];
+    vst[6 * p + lane][1] = stg[(6 + lane) * kStRow + kStOrg + nvs - 1];
+  }
+  // ---- lanes = outputs again: the block a window starts in (the filter's own coefficients from q0 on), the block it
+  // ends in (rows 12 .. 15 of the tile) and the three sums ----------------------------------------------------------------
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    const int b = 2 * p + sub;
+    double sr = 0., si = 0.;
     {
       const double* xl = win + t_left[b] + lane;
       const int g0 = t_q0[b] >> 3;                     // (whole groups of eight in front of the window are skipped)
@@ -688,69 +811,13 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
       if (g0 <= 2) bs_left_group<2>(xl, lc, sr, si);
       bs_left_group<3>(xl, lc, sr, si);
     }
-    double hn[6];                                      // what the history will hold after this tile
-    // V(-1) of the three chains: from the history (lane J - 1 of its sums) on a launch's first tile, else from the
-    // previous tile.  Decided once for the three, and the new V stored once after them: the chains' own work then is
-    // one basic block, and the scheduler fills each chain's DPP latencies with the other two.
-    double vr[3], vi[3];
-    if (first_tile) {
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        double ar = h[sub][2 * e], ai = h[sub][2 * e + 1];
-        bs_chain(ar, ai, 0., 0., pwr[3 * sub + e], pwi[3 * sub + e], lane, z15, z31);
-        vr[e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ar), J - 1),
-                                 __builtin_amdgcn_readlane(__double2loint(ar), J - 1));
-        vi[e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ai), J - 1),
-                                 __builtin_amdgcn_readlane(__double2loint(ai), J - 1));
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        vr[e] = vst[6 * p + 3 * sub + e][0];
-        vi[e] = vst[6 * p + 3 * sub + e][1];
-      }
-    }
-    double wr[3], wi[3];
+    const double* col = stg + kStOrg + lane;
+    sr += col[(12 + sub) * kStRow];
+    si += col[(14 + sub) * kStRow];
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
-      const int c = 3 * sub + e;
-      // enter(t) - rot^J enter(t - J)
-      const bool in_tile = lane >= J;
-      const double er = urow[2 * e * kStRow], ei = urow[(2 * e + 1) * kStRow];
-      const double pr = in_tile ? urow[2 * e * kStRow - J] : h[sub][2 * e];
-      const double pi = in_tile ? urow[(2 * e + 1) * kStRow - J] : h[sub][2 * e + 1];
-      double re = fma(-rjr[c], pr, fma(rji[c], pi, er));
-      double im = fma(-rjr[c], pi, fma(-rji[c], pr, ei));
-      bs_chain(re, im, vr[e], vi[e], pwr[c], pwi[c], lane, z15, z31);
-      // the sums after the tile's last valid output go on to the next tile
-      wr[e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(re), nvs - 1),
-                               __builtin_amdgcn_readlane(__double2loint(re), nvs - 1));
-      wi[e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(im), nvs - 1),
-                               __builtin_amdgcn_readlane(__double2loint(im), nvs - 1));
-      sr += re;
-      si += im;
-      // history: lane i < J <- enter(nvs - J + i)
-      const int src = nvs - J + lane;
-      hn[2 * e] = urow[2 * e * kStRow + (src >= 0 ? src : 0) - lane];
-      hn[2 * e + 1] = urow[(2 * e + 1) * kStRow + (src >= 0 ? src : 0) - lane];
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        vst[6 * p + 3 * sub + e][0] = wr[e];
-        vst[6 * p + 3 * sub + e][1] = wi[e];
-      }
-    }
-    if (nvs < J) {                                     // a short tile (the last of a launch): part of the old history stays
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const double old = __shfl(h[sub][r], lane + nvs, 64);
-        hn[r] = nvs - J + lane >= 0 ? hn[r] : old;
-      }
-    }
-    if (lane < J) {
-#pragma unroll
-      for (int r = 0; r < 6; ++r) hist[(b * 6 + r) * kBsHist + lane] = hn[r];
+      sr += col[(3 * sub + e) * kStRow];
+      si += col[(6 + 3 * sub + e) * kStRow];
     }
     yr[sub] = sr;
     yi[sub] = si;
@@ -1095,6 +1162,14 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
   const double fm_noise = tid < kFbBands ? bt->internal_noise[tid] : 0., fm_ac = tid < kFbBands ? bt->ear_tc[tid] : 0.;
   const double alias_re = ((kdouble*)(const void*)fb->h_re)[1], alias_im = ((kdouble*)(const void*)fb->h_im)[1];   // (scalar registers)
   const int tid_k = tid, lane_k = lane, wv_k = wv;
+  if constexpr (sizeof(WT) == 8) {
+    // FP64 engine: the staging rows of the block-sum form live in A, and some of their entries are read before anything
+    // of this kernel has been written there (outputs 61 .. 63 of rows the tile shifts by two columns); what is computed
+    // from them is thrown away or multiplied by zero (bs_pair) -- so it must be finite, whatever the workgroup before
+    // this one left in LDS.  Once per workgroup; the first tile's barrier comes before any use.
+    double2* az = reinterpret_cast<double2*>(&sh.a.re[0][0]);
+    for (int i = tid; i < 2 * kFbBands * kACols / 2; i += 256) az[i] = make_double2(0., 0.);
+  }
   for (unsigned b0 = 0; b0 < nb_mine; b0 += kTileBlocks) {
     // The thread's indices are re-derived (as far as the compiler can tell) in every tile: otherwise it computes the
     // LDS addresses of ALL phases once in front of the loop -- some two hundred registers, most of which the FP64

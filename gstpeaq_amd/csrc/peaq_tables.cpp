@@ -319,7 +319,7 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
           row[2 * i + 1] = (double)(-gi[i] * std::sin(ph));
         }
         own(32 * cR[b] + q - 727, row[6], row[7]);
-        for (int ty = 0; ty < 8; ++ty) fb.bs_coef[p][q / 4][(8 * sub + ty) + 16 * (q & 3)] = row[ty];
+        for (int ty = 0; ty < 8; ++ty) fb.bs_coef[p][q / 4][bs_row(sub, ty) + 16 * (q & 3)] = row[ty];
         own(32 * cL[b] + q - 727, fb.bs_left[b][q][0], fb.bs_left[b][q][1]);
       }
       for (int i = 0; i < 3; ++i) {
@@ -332,6 +332,22 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
           const long double ph = 32.0L * wi[i] * (long double)(l + 1);
           fb.bs_pow[3 * b + i][l][0] = (double)std::cos(ph);
           fb.bs_pow[3 * b + i][l][1] = (double)std::sin(ph);
+        }
+        // the lane-per-(chain, segment) evaluation of the running sums (peaq_device.h, kBsSeg)
+        const int J = fb.bs_whole[b], sg = (kBsSeg - J % kBsSeg) % kBsSeg, c = 3 * sub + i;
+        fb.bs_seg_s[b] = sg;
+        for (int l = 0; l < 64; ++l) {
+          if (std::min(l >> 3, 5) != c) continue;
+          const int g = l & 7;
+          auto put = [&](int e, long double steps, bool zero) {
+            const long double ph = 32.0L * wi[i] * steps;
+            fb.bs_seg[p][e][l][0] = zero ? 0. : (double)std::cos(ph);
+            fb.bs_seg[p][e][l][1] = zero ? 0. : (double)std::sin(ph);
+          };
+          for (int lv = 0; lv < 3; ++lv) put(lv, (long double)(kBsSeg << lv), g < (1 << lv));
+          put(3, (long double)(kBsSeg * g - sg), false);
+          put(4, 1.0L, false);
+          put(5, (long double)J, false);
         }
       }
     }
@@ -439,30 +455,82 @@ double fb_tables_selfcheck() {
       auto row_dot = [&](int ty, int col) {                // one row of the pair's tile on window column col
         double acc = 0.;
         for (int q = 0; q < 32; ++q)
-          acc += fb.bs_coef[p][q / 4][(8 * sub + ty) + 16 * (q & 3)] * (col >= 0 ? x[32 * col + q] : 0.);
+          acc += fb.bs_coef[p][q / 4][bs_row(sub, ty) + 16 * (q & 3)] * (col >= 0 ? x[32 * col + q] : 0.);
         return acc;
       };
       for (int i = 0; i < 3; ++i) {
-        const double (&rot)[2][2] = fb.bs_rot[3 * b + i];
-        std::vector<double> er(kOut + J), ei(kOut + J);    // enter values of the outputs -J .. kOut - 1
-        for (int t = -J; t < kOut; ++t) {
+        // the running sums the way the kernel evaluates them (peaq_fb.hip, bs_pair): eight lanes per chain, a lane takes
+        // kBsSeg consecutive outputs from kBsSeg g - s on; local sums with nothing carried in, a weighted scan over the
+        // segments, then the outputs themselves
+        const int c = 3 * sub + i, sg = fb.bs_seg_s[b];
+        constexpr int kSpan = 8 * kBsSeg;
+        std::vector<double> er(kSpan + J + kBsSeg, 0.), ei(kSpan + J + kBsSeg, 0.);   // enter values of the outputs -J .. kSpan - 1
+        for (int t = -J; t < kSpan; ++t) {
           const int ch = fb.bs_col_head[p] + t + fb.bs_off_enter[b];
+          if (ch >= kCols) continue;                       // (beyond the window: outputs >= 60, never looked at)
           er[t + J] = row_dot(2 * i, ch);
           ei[t + J] = row_dot(2 * i + 1, ch);
         }
-        double vr = 0., vi = 0.;
-        for (int t = -J; t < kOut; ++t) {                  // run-in over the history with nothing leaving, then the tile
-          double ur = er[t + J], ui = ei[t + J];
-          if (t >= 0) {                                     // leave(t) = rot^J enter(t - J)
-            ur -= rot[1][0] * er[t] - rot[1][1] * ei[t];
-            ui -= rot[1][0] * ei[t] + rot[1][1] * er[t];
+        auto enter = [&](int t, double& r, double& m) {    // zeros in front of the history, like the rows' front slots
+          r = t >= -J ? er[t + J] : 0.;
+          m = t >= -J ? ei[t + J] : 0.;
+        };
+        const double (&rt)[2][2] = fb.bs_rot[3 * b + i];
+        double v_r = 0., v_i = 0.;                         // V(-1) from the history (the kernel: on a launch's first tile)
+        for (int t = -J; t < 0; ++t) {
+          const double nr = rt[0][0] * v_r - rt[0][1] * v_i + er[t + J], ni = rt[0][0] * v_i + rt[0][1] * v_r + ei[t + J];
+          v_r = nr;
+          v_i = ni;
+        }
+        double dr8[8][kBsSeg], di8[8][kBsSeg], tr[8], ti[8];
+        for (int g = 0; g < 8; ++g) {
+          const int lane = 8 * c + g, t0 = kBsSeg * g - sg;
+          const double rjr = fb.bs_seg[p][5][lane][0], rji = fb.bs_seg[p][5][lane][1];
+          const double rr = fb.bs_seg[p][4][lane][0], ri = fb.bs_seg[p][4][lane][1];
+          if (t0 < J && t0 + kBsSeg > J) return 1.;        // output J must start a segment
+          for (int k = 0; k < kBsSeg; ++k) {
+            double e_r, e_i, l_r, l_i;
+            enter(t0 + k < 0 ? -J - 1 : t0 + k, e_r, e_i);
+            enter(t0 + k < 0 ? -J - 1 : t0 + k - J, l_r, l_i);
+            dr8[g][k] = e_r - (rjr * l_r - rji * l_i);
+            di8[g][k] = e_i - (rjr * l_i + rji * l_r);
           }
-          const double nr = rot[0][0] * vr - rot[0][1] * vi + ur, ni = rot[0][0] * vi + rot[0][1] * vr + ui;
-          vr = nr;
-          vi = ni;
-          if (t >= 0) {
-            yr[t] += vr;
-            yi[t] += vi;
+          tr[g] = dr8[g][0];
+          ti[g] = di8[g][0];
+          for (int k = 1; k < kBsSeg; ++k) {
+            const double nr = rr * tr[g] - ri * ti[g] + dr8[g][k], ni = rr * ti[g] + ri * tr[g] + di8[g][k];
+            tr[g] = nr;
+            ti[g] = ni;
+          }
+        }
+        for (int lv = 0; lv < 3; ++lv) {                   // Hillis-Steele over the eight segments
+          double nr[8], ni[8];
+          for (int g = 0; g < 8; ++g) {
+            const int lane = 8 * c + g, src = g - (1 << lv);
+            const double wr = fb.bs_seg[p][lv][lane][0], wi_ = fb.bs_seg[p][lv][lane][1];
+            const double sr_ = src >= 0 ? tr[src] : 123., si_ = src >= 0 ? ti[src] : -77.;   // (whatever the neighbouring group holds)
+            nr[g] = tr[g] + (wr * sr_ - wi_ * si_);
+            ni[g] = ti[g] + (wr * si_ + wi_ * sr_);
+          }
+          for (int g = 0; g < 8; ++g) {
+            tr[g] = nr[g];
+            ti[g] = ni[g];
+          }
+        }
+        for (int g = 0; g < 8; ++g) {
+          const int lane = 8 * c + g, t0 = kBsSeg * g - sg;
+          const double kr = fb.bs_seg[p][3][lane][0], ki = fb.bs_seg[p][3][lane][1];
+          const double rr = fb.bs_seg[p][4][lane][0], ri = fb.bs_seg[p][4][lane][1];
+          double vr = (g > 0 ? tr[g - 1] : 0.) + (kr * v_r - ki * v_i), vi = (g > 0 ? ti[g - 1] : 0.) + (kr * v_i + ki * v_r);
+          for (int k = 0; k < kBsSeg; ++k) {
+            const double nr = rr * vr - ri * vi + dr8[g][k], ni = rr * vi + ri * vr + di8[g][k];
+            vr = nr;
+            vi = ni;
+            const int t = t0 + k;
+            if (t >= 0 && t < kOut) {
+              yr[t] += vr;
+              yi[t] += vi;
+            }
           }
         }
       }
