@@ -64,7 +64,7 @@ constexpr int kBsBands  = 24;
 constexpr int kBsPairs  = kBsBands / 2;
 constexpr int kBsChains = kBsBands * 3;
 constexpr int kBsHistOrg = 8;     // a history row starts with eight zeros (outputs in front of a window's first whole block)
-constexpr int kBsHist   = kBsHistOrg + 44;   // ... followed by up to 44 enter values: the longest filter's whole blocks
+constexpr int kBsHist   = kBsHistOrg + 48;   // ... followed by up to 45 enter values: the longest run of whole blocks
 // Rows of a pair's 16-row tile: the enter rows first (re of the six chains -- chain = 3 * band-in-pair + exponential --,
 // then im), then the rows of the block the windows end in (re of both bands, im of both bands).  ty as in the
 // tables' construction: 2 * exponential + {re, im} for ty < 6, 6 / 7 = re / im of the end block.
@@ -163,6 +163,11 @@ struct FbTables {               // fbearmodel.c:57-61,182-225
   int    bs_off_enter[kBsBands];        // column of band b's enter rows at output t: bs_col_head + t + this (edge rows: + 1)
   int    bs_col_left[kBsBands];         // cL: column (at t = 0) of the block the window starts in
   int    bs_left_q0[kBsBands];          // first sample of that block inside the window
+  // When fewer than half of that block's samples lie OUTSIDE the window (q0 < 16), the block is counted among the
+  // whole ones (bs_whole = J + 1) and what it has too much -- samples 0 .. q0 - 1 times the periodic continuation
+  // of the window, which is what the three exponentials add up to there -- is taken off instead: bs_left then holds
+  // minus those coefficients.  Either way at most 16 taps; bs_left_g = the groups of eight taps that are not all zero.
+  int    bs_left_g[kBsBands][2];        // [first group, end)
   int    bs_whole[kBsBands];            // J = cR - 1 - cL whole columns
   // A operands: [pair][K step][lane = row + 16 (k mod 4)], row = 8 (band in pair) + type,
   // type 0..5 = re, im of the three exponentials' enter rows, 6, 7 = re, im of the block the window ends in

@@ -613,6 +613,20 @@ __device__ __forceinline__ void bs_left_group(const double* __restrict__ xl, con
   }
 }
 
+#ifdef PEAQ_FB_PROFILE
+__device__ unsigned long long g_fb_prof[4 * 16 + 4];
+#endif
+// -DPEAQ_FB_SUBPROF (with -DPEAQ_FB_PROFILE): the steps of bs_pair are timed into slots 5 .. 11 in place of the tile's later phases
+#ifdef PEAQ_FB_SUBPROF
+#define BS_MARK(i)                                                                       \
+  do {                                                                                   \
+    const unsigned long long now_ = __builtin_readcyclecounter();                        \
+    if (lane == 0 && (blockIdx.x & 15) == 5) atomicAdd(&g_fb_prof[(threadIdx.x >> 6) * 16 + (i)], now_ - bs_t_); \
+    bs_t_ = __builtin_readcyclecounter();                                                \
+  } while (0)
+#else
+#define BS_MARK(i) do { } while (0)
+#endif
 // one pair of bands (2 p, 2 p + 1): their filter outputs at the tile's outputs lane = 0 .. 59 -> (yr, yi)[band in pair];
 // a holds the pair's A operands on entry and the next pair's on return
 __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* __restrict__ stg, double (*vst)[2],
@@ -625,9 +639,12 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
   kint* t_head = (kint*)(const void*)fb->bs_col_head;
   kint* t_off = (kint*)(const void*)fb->bs_off_enter;
   kint* t_left = (kint*)(const void*)fb->bs_col_left;
-  kint* t_q0 = (kint*)(const void*)fb->bs_left_q0;
+  kint* t_lg = (kint*)(const void*)fb->bs_left_g;
   kint* t_whole = (kint*)(const void*)fb->bs_whole;
   kint* t_segs = (kint*)(const void*)fb->bs_seg_s;
+#ifdef PEAQ_FB_SUBPROF
+  unsigned long long bs_t_ = __builtin_readcyclecounter();
+#endif
   const int col_head = t_head[p];
   const int J0 = t_whole[2 * p], J1 = t_whole[2 * p + 1];
   // the lane's part in the running sums: chain c of the pair (3 * band + exponential; lanes 48 .. 63 repeat chain 5),
@@ -696,6 +713,7 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
   lcoef[lane] = cl[0];                                 // the first blocks' coefficients where every lane can read them
   lcoef[64 + lane] = cl[1];
   wave_lds_fence();
+  BS_MARK(5);   // loads issued, tile, staging writes
   if (first_tile) {
     // a launch's first tile: V(-1) of the six chains from the history, lanes = history entries (one prefix scan each)
     double z15 = 0., z31 = 0.;
@@ -732,27 +750,41 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
     dr[k] = fma(-rj.x, lr[k], fma(rj.y, li[k], erow[k]));
     di[k] = fma(-rj.x, li[k], fma(-rj.y, lr[k], erow[6 * kStRow + k]));
   }
-  // the history after this tile: lane i < J <- enter(nvs - J + i) -- before the sums take the rows' place
+  BS_MARK(6);   // first-tile branch, d
+  // the history after this tile: lane i < J <- enter(nvs - J + i) -- before the sums take the rows' place.  (Two copies
+  // of the loop: a tile shorter than J -- the last of a launch at most -- keeps part of the old history and has to load
+  // it; in one copy, the wait for that load would stand in every tile's path, and it waits for ALL loads in flight,
+  // the next pair's coefficients included.)
+  if (nvs >= max(J0, J1)) {
 #pragma unroll
-  for (int sub = 0; sub < 2; ++sub) {
-    const int b = 2 * p + sub, J = sub ? J1 : J0;
-    const int src = nvs - J + lane;
-    double hn[6];
+    for (int sub = 0; sub < 2; ++sub) {
+      const int J = sub ? J1 : J0;
+      const double* src = stg + kStOrg + nvs - J + lane;
+      double hn[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) hn[r] = stg[bs_row(sub, r) * kStRow + kStOrg + max(src, 0)];
-    double* hrow = hist + (size_t)b * 6 * kBsHist + kBsHistOrg;
-    if (nvs < J) {                                     // a short tile (the last of a launch): part of the old history stays
+      for (int r = 0; r < 6; ++r) hn[r] = src[bs_row(sub, r) * kStRow];
+      double* hrow = hist + (size_t)(2 * p + sub) * 6 * kBsHist + kBsHistOrg;
+      if (lane < J) {
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const double old = hrow[r * kBsHist + min(lane + nvs, kBsHist - kBsHistOrg - 1)];
-        hn[r] = src >= 0 ? hn[r] : old;
+        for (int r = 0; r < 6; ++r) hrow[r * kBsHist + lane] = hn[r];
       }
     }
-    if (lane < J) {
-#pragma unroll
-      for (int r = 0; r < 6; ++r) hrow[r * kBsHist + lane] = hn[r];
+  } else {
+#pragma unroll 1
+    for (int sub = 0; sub < 2; ++sub) {
+      const int J = sub ? J1 : J0;
+      const int src = nvs - J + lane;
+      double* hrow = hist + (size_t)(2 * p + sub) * 6 * kBsHist + kBsHistOrg;
+#pragma unroll 1
+      for (int r = 0; r < 6; ++r) {
+        const double fresh = stg[bs_row(sub, 0) * kStRow + (r >> 1) * kStRow + (r & 1) * 6 * kStRow + kStOrg + max(src, 0)];
+        const double old = hrow[r * kBsHist + min(lane + nvs, kBsHist - kBsHistOrg - 1)];
+        const double v = src >= 0 ? fresh : old;
+        if (lane < J) hrow[r * kBsHist + lane] = v;
+      }
     }
   }
+  BS_MARK(7);   // history update
   // the segment's sum with nothing carried in (Horner in rot), ...
   double tr = dr[0], ti = di[0];
 #pragma unroll
@@ -782,6 +814,7 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
     vr = fma(m, pr_, fma(kp.x, v.x, -kp.y * v.y));
     vi = fma(m, pi_, fma(kp.x, v.y, kp.y * v.x));
   }
+  BS_MARK(8);   // Horner, scan, carry-in
   // ... and the sums themselves, written over the enter values
 #pragma unroll
   for (int k = 0; k < kBsSeg; ++k) {
@@ -796,6 +829,7 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
     vst[6 * p + lane][0] = stg[lane * kStRow + kStOrg + nvs - 1];
     vst[6 * p + lane][1] = stg[(6 + lane) * kStRow + kStOrg + nvs - 1];
   }
+  BS_MARK(9);   // final pass, V writes, vst
   // ---- lanes = outputs again: the block a window starts in (the filter's own coefficients from q0 on), the block it
   // ends in (rows 12 .. 15 of the tile) and the three sums ----------------------------------------------------------------
 #pragma unroll
@@ -804,12 +838,12 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
     double sr = 0., si = 0.;
     {
       const double* xl = win + t_left[b] + lane;
-      const int g0 = t_q0[b] >> 3;                     // (whole groups of eight in front of the window are skipped)
+      const int ga = t_lg[2 * b], gb = t_lg[2 * b + 1];   // the groups of eight taps that count (at most two, FbTables::bs_left_g)
       const double* lc = lcoef + 64 * sub;
-      if (g0 <= 0) bs_left_group<0>(xl, lc, sr, si);
-      if (g0 <= 1) bs_left_group<1>(xl, lc, sr, si);
-      if (g0 <= 2) bs_left_group<2>(xl, lc, sr, si);
-      bs_left_group<3>(xl, lc, sr, si);
+      if (ga <= 0 && 0 < gb) bs_left_group<0>(xl, lc, sr, si);
+      if (ga <= 1 && 1 < gb) bs_left_group<1>(xl, lc, sr, si);
+      if (ga <= 2 && 2 < gb) bs_left_group<2>(xl, lc, sr, si);
+      if (3 < gb) bs_left_group<3>(xl, lc, sr, si);
     }
     const double* col = stg + kStOrg + lane;
     sr += col[(12 + sub) * kStRow];
@@ -822,6 +856,7 @@ __device__ __forceinline__ void bs_pair(const double* __restrict__ win, double* 
     yr[sub] = sr;
     yi[sub] = si;
   }
+  BS_MARK(10);  // left edges, assembly
   wave_lds_fence();                                    // the next pair's tile overwrites the staging rows
 }
 
@@ -1025,11 +1060,15 @@ __device__ __forceinline__ void spread_up(BankLds<WT>& sh, const double (&re)[10
 // Phase timing for tools/fb_profile.py (development builds with -DPEAQ_FB_PROFILE only): cycles between
 // consecutive marks, summed per wave role over one sampled workgroup in 16.
 #ifdef PEAQ_FB_PROFILE
-__device__ unsigned long long g_fb_prof[4 * 16 + 4];
+#ifdef PEAQ_FB_SUBPROF
+#define FB_SLOT_OK(i) ((i) < 5 || (i) > 10)
+#else
+#define FB_SLOT_OK(i) true
+#endif
 #define FB_MARK(i)                                                                       \
   do {                                                                                   \
     const unsigned long long now_ = __builtin_readcyclecounter();                        \
-    if (lane == 0 && (blockIdx.x & 15) == 5) atomicAdd(&g_fb_prof[wv * 16 + (i)], now_ - prof_t_); \
+    if (FB_SLOT_OK(i) && lane == 0 && (blockIdx.x & 15) == 5) atomicAdd(&g_fb_prof[wv * 16 + (i)], now_ - prof_t_); \
     prof_t_ = __builtin_readcyclecounter();                                              \
   } while (0)
 #else

@@ -283,8 +283,10 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
       const int half = kLen[b] / 2;
       cL[b] = (728 - half) >> 5;
       cR[b] = (726 + half) >> 5;
-      fb.bs_whole[b] = cR[b] - 1 - cL[b];
-      if (fb.bs_whole[b] < 1 || fb.bs_whole[b] > 44) std::abort();
+      fb.bs_left_q0[b] = (728 - half) & 31;
+      // (peaq_device.h, bs_left_g: with q0 < 16 the block the window starts in counts as whole)
+      fb.bs_whole[b] = cR[b] - 1 - cL[b] + (fb.bs_left_q0[b] < 16 ? 1 : 0);
+      if (fb.bs_whole[b] < 1 || fb.bs_whole[b] > kBsHist - kBsHistOrg) std::abort();
     }
     for (int p = 0; p < kBsPairs; ++p) {
       const int b0 = 2 * p, b1 = 2 * p + 1;
@@ -310,7 +312,10 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
         vi = m == 0 ? 0. : (m > 0 ? fb.h_im[fb.coef_off[b] + n] : -fb.h_im[fb.coef_off[b] + n]);
       };
       fb.bs_col_left[b] = cL[b];
-      fb.bs_left_q0[b] = (728 - half) & 31;
+      const int q0 = fb.bs_left_q0[b];
+      const bool counted_whole = q0 < 16;
+      fb.bs_left_g[b][0] = counted_whole ? 0 : q0 >> 3;
+      fb.bs_left_g[b][1] = counted_whole ? (q0 + 7) >> 3 : 4;
       for (int q = 0; q < 32; ++q) {
         double row[8];
         for (int i = 0; i < 3; ++i) {                      // a block enters the running sums as column cR - 1
@@ -320,7 +325,18 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
         }
         own(32 * cR[b] + q - 727, row[6], row[7]);
         for (int ty = 0; ty < 8; ++ty) fb.bs_coef[p][q / 4][bs_row(sub, ty) + 16 * (q & 3)] = row[ty];
-        own(32 * cL[b] + q - 727, fb.bs_left[b][q][0], fb.bs_left[b][q][1]);
+        if (!counted_whole) {
+          own(32 * cL[b] + q - 727, fb.bs_left[b][q][0], fb.bs_left[b][q][1]);
+        } else {                                          // minus the exponentials' sum where the window has ended
+          long double sr_ = 0, si_ = 0;
+          for (int i = 0; i < 3; ++i) {
+            const long double ph = wi[i] * (long double)(32 * cL[b] + q - 727);
+            sr_ += gi[i] * std::cos(ph);
+            si_ -= gi[i] * std::sin(ph);
+          }
+          fb.bs_left[b][q][0] = q < q0 ? (double)-sr_ : 0.;
+          fb.bs_left[b][q][1] = q < q0 ? (double)-si_ : 0.;
+        }
       }
       for (int i = 0; i < 3; ++i) {
         for (int k = 0; k < 2; ++k) {
@@ -538,7 +554,7 @@ double fb_tables_selfcheck() {
         const int ch = fb.bs_col_head[p] + t + fb.bs_off_enter[b] + 1, cl = fb.bs_col_left[b] + t;
         yr[t] += row_dot(6, ch);
         yi[t] += row_dot(7, ch);
-        for (int q = fb.bs_left_q0[b]; q < 32; ++q) {
+        for (int q = 8 * fb.bs_left_g[b][0]; q < 8 * fb.bs_left_g[b][1]; ++q) {
           yr[t] += fb.bs_left[b][q][0] * x[32 * cl + q];
           yi[t] += fb.bs_left[b][q][1] * x[32 * cl + q];
         }
