@@ -381,7 +381,10 @@ static const size_t kRecordBudget = (size_t)1536 << 20;   // HBM for per-frame r
 // Filter-bank blocks per launch (a multiple of the tile of 10) and the HBM one buffer of high-passed rows
 // may take.  Long launches pay: per block the bank kernel costs 0.150 ms in launches of 320 blocks, 0.142 at
 // 840 (fewer drained-CU tails, fewer pipeline hand-overs) -- 4096 stereo pairs x 10 s: 4.57 -> 4.74 M
-// frame-pairs/s for 2 x 21 GB of rows + 18 GB of block records, small change on a 288 GB device.
+// frame-pairs/s for 2 x 21 GB of rows + 18 GB of block records, small change on a 288 GB device.  Round 4, FP64
+// engine, same job: 420 / 630 / 840 / 1250 blocks per launch = 5.14 / 5.19 / 5.20 / 5.26 M -- but 1250 means
+// 2 x 32 GB of rows + 27 GB of records per context that has run such a batch, and a process with three contexts
+// (the parity suite has) no longer leaves room for another process on the device: 840 stays.
 #ifndef PEAQ_FB_CHUNK
 #define PEAQ_FB_CHUNK 840
 #endif
