@@ -252,6 +252,26 @@ def test_session_streaming_equals_batch(gpu, advanced, fir_mode):
     s.close()
 
 
+def test_session_fed_one_filterbank_block_at_a_time(gpu, fir_mode):
+    """Advanced version, a launch per 192-sample block: every tile of the filter bank is shorter than the filters'
+    whole-block counts, so the block-sum form (FP64 engine) keeps most of its history from launch to launch
+    (peaq_fb.hip, bs_pair: the short-tile path) and re-anchors its running sums every block; the split-FP16
+    engine's window head spans eight launches.  Same results as the batch path."""
+    import gstpeaq_amd
+    ref, test = case_defs.make_inputs(dict(kind="synth", seed=11, channels=1, n=40000))
+    whole = gpu.run_batch([(ref, test)], 1, 1)[0]
+    s = gstpeaq_amd.Session(gpu.ctx(), 1, 1)
+    for lo in range(0, len(ref), 192):
+        s.push_ref(ref[lo:lo + 192])
+        s.push_test(test[lo:lo + 192])
+    s.flush()
+    got = s.results()
+    s.close()
+    assert got["fb_blocks"] == whole["fb_blocks"]
+    np.testing.assert_allclose(got["movs"], whole["movs"], rtol=gpu.tol("chunks"), atol=0)
+    assert abs(got["odg"] - whole["odg"]) <= gpu.tol("chunks")
+
+
 @pytest.mark.parametrize("advanced", [0, 1])
 def test_empty_and_tiny_pairs_inside_a_batch(gpu, advanced, fir_mode):
     """an element that reaches EOS without data reports NaN (empty accumulators, movaccum.c:438-481);
