@@ -1137,7 +1137,10 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
   const BandTables* __restrict__ bt = a.bands;
   const FbTables* __restrict__ fb = a.fb;
   const size_t row_len = a.hp_row_stride;
-  const size_t row_valid = (size_t)kFbRing + (size_t)a.blocks_per_launch * kFbFrame;
+  // what the high-pass walk has written of this signal's row in this launch: its OWN blocks.  (Not the launch's:
+  // behind a shorter session's or pair's blocks the row holds whatever the memory held before -- outputs that do
+  // not exist are computed from it, and the FP64 engine's running sums need those to be finite, bs_pair.)
+  const size_t row_valid = (size_t)kFbRing + (size_t)nb_mine * kFbFrame;
   const double* __restrict__ row = a.hp_scratch + (size_t)state_idx * row_len;
   FbSignalState* __restrict__ st = a.fbstate + state_idx;
   // Scale of the split-FP16 operands: the launch's power of two (full scale at 2^10..2^11, 30 dB of headroom)
@@ -1437,11 +1440,16 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     // ---- phase 4: rectification + backward masking at block rate (fbearmodel.c:357-382), wave-local: a
     // wave takes the ten bands it carried through phase 2, first E0 = re^2 + im^2 for all time points (lane =
     // time, written over re), then one (band, block) per lane: eleven reads of E0, no barrier in between ------
+    {
+      double x[10], y[10];                           // (all reads first: written as read - square - write per band,
+#pragma unroll                                       // every band waited for its own LDS round trip)
+      for (int i = 0; i < 10; ++i) {
+        const int b = wave_band(wv, i);
+        x[i] = sh.a.re[b][lane];
+        y[i] = sh.a.im[b][lane];
+      }
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const int b = wave_band(wv, i);
-      const double x = sh.a.re[b][lane], y = sh.a.im[b][lane];
-      sh.a.re[b][lane] = x * x + y * y;
+      for (int i = 0; i < 10; ++i) sh.a.re[wave_band(wv, i)][lane] = x[i] * x[i] + y[i] * y[i];
     }
     wave_lds_fence();
     double hnew[2] = {0., 0.};
@@ -1451,13 +1459,16 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
       if (item < 100) {
         const int i = item / 10, k = item - 10 * i;
         const int b = wave_band(wv, i);
-        // E0 of sub-sample s (negative: previous tile)
-        auto e0 = [&](int s) { return s < 0 ? sh.hist[b][10 + s] : sh.a.re[b][s]; };
+        // E0 of sub-sample s (negative: previous tile): one read through a selected address
+        auto e0 = [&](int s) { return *(s < 0 ? &sh.hist[b][10 + s] : &sh.a.re[b][s]); };
         const int s_new = 6 * k + 5;                 // newest sub-sample of block k
+        double tap[11];
+#pragma unroll
+        for (int t = 0; t < 11; ++t) tap[t] = e0(s_new - t);
         double e1 = 0.;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) e1 += (e0(s_new - t) + e0(s_new - 10 + t)) * kBackMask[t];
-        e1 += e0(s_new - 5) * kBackMask[5];
+        for (int t = 0; t < 5; ++t) e1 += (tap[t] + tap[10 - t]) * kBackMask[t];
+        e1 += tap[5] * kBackMask[5];
         sh.e1[b][k] = e1;
         // history for the next tile: the 10 newest VALID sub-samples, oldest first
         hnew[rep] = e0(nvs - 10 + k);
@@ -1476,11 +1487,27 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     // the blocks is walked by one thread per band into LDS; then all threads write the records --------
     if (tid < kFbBands) {
       const double noise = fm_noise, ac = fm_ac;
-      for (unsigned bl = 0; bl < nvb; ++bl) {
-        const double unsm = sh.e1[tid][bl] + noise;
-        exc = ac * exc + (1. - ac) * unsm;
-        sh.e1[tid][bl] = unsm;
-        sh.ex[tid][bl] = exc;
+      if (nvb == kTileBlocks) {
+        // a full tile: the ten values first, then the recurrence in registers, then the results -- as a loop of
+        // read - two multiply-adds - write every block waited for its own LDS round trip (1.6 k cycles for 20
+        // multiply-adds, with three waves at the barrier)
+        double u[kTileBlocks];
+#pragma unroll
+        for (int bl = 0; bl < kTileBlocks; ++bl) u[bl] = sh.e1[tid][bl];
+#pragma unroll
+        for (int bl = 0; bl < kTileBlocks; ++bl) {
+          const double unsm = u[bl] + noise;
+          exc = ac * exc + (1. - ac) * unsm;
+          sh.e1[tid][bl] = unsm;
+          sh.ex[tid][bl] = exc;
+        }
+      } else {
+        for (unsigned bl = 0; bl < nvb; ++bl) {
+          const double unsm = sh.e1[tid][bl] + noise;
+          exc = ac * exc + (1. - ac) * unsm;
+          sh.e1[tid][bl] = unsm;
+          sh.ex[tid][bl] = exc;
+        }
       }
     }
     __syncthreads();
@@ -1495,7 +1522,8 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     PEAQ_DEV_DUMP_FIR_WRITE
 #endif
     // the next tile's new samples have arrived: into the window (its old columns 45.. are dead since the shift; the
-    // barrier of the next tile's phase 0 stands between these writes and the filters)
+    // barrier of the next tile's phase 0 stands between these writes and the filters).  (Measured: in front of the
+    // records' stores this phase takes 0.5 k cycles longer, and touching the lines early from phase 4 does not help.)
     if (b0 + kTileBlocks < nb_mine) {
 #pragma unroll
       for (int q = 0; q < kPre; ++q) {
