@@ -1521,6 +1521,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
 #ifdef PEAQ_DEV_DUMP_FIR
     PEAQ_DEV_DUMP_FIR_WRITE
 #endif
+    FB_MARK(15);
     // the next tile's new samples have arrived: into the window (its old columns 45.. are dead since the shift; the
     // barrier of the next tile's phase 0 stands between these writes and the filters).  (Measured: in front of the
     // records' stores this phase takes 0.5 k cycles longer, and touching the lines early from phase 4 does not help.)

@@ -17,7 +17,7 @@ PHASES = ["0 window + zero A + barrier", "1 FIR (own run of K steps)", "2 barrie
           "4 shift window, request next", "5 log/exp/slope scan (10 bands)", "6 upward spreading", "7 barrier",
           "8 downward spreading + barrier", "9 backward masking + barrier", "10 history + barrier",
           "11 forward masking + barrier", "12 records",
-          "13 FP64 engine: block-sum form of bands 0..23 (inside 1)", "14 FP64 engine: barrier, results -> A (inside 1)"]
+          "13 FP64 engine: block-sum form of bands 0..23 (inside 1)", "14 FP64 engine: barrier, results -> A (inside 1)", "15 records: reads and stores (12 = the rest: next window into LDS)"]
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 MODE = sys.argv[2] if len(sys.argv) > 2 else "f64"     # "f64" (the engine's default) | "f16x3" | "f32"
 ctx = gstpeaq_amd.Context(0)
