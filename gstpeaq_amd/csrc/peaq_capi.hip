@@ -102,6 +102,14 @@ struct DevBuf {
     cap = 0;
     hipError_t e = hipMalloc(&p, bytes);
     if (e == hipSuccess) cap = bytes;
+    // PEAQ_AMD_POISON=1 (tests/test_gpu_poison.py): every workspace starts as NaNs (all bits set) instead of whatever
+    // the allocator hands out -- fresh memory is zero, recycled memory is not; nothing may depend on either.  State
+    // that has to start from zero is set to zero explicitly where it is created.
+    static const bool poison = [] { const char* v = std::getenv("PEAQ_AMD_POISON"); return v && *v && *v != '0'; }();
+    if (e == hipSuccess && poison) {
+      e = hipMemset(p, 0xFF, bytes);
+      if (e == hipSuccess) e = hipDeviceSynchronize();   // (the owners' own streams do not wait for the null stream)
+    }
     return e;
   }
   void release() {
