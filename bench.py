@@ -177,13 +177,15 @@ def result_deltas(gpu_rows, cpu, advanced):
 
 # ----------------------------------------------------------------------------------------------
 def source_hash():
-    """sha256 over the kernel sources (gstpeaq_amd/csrc/*) with comments and white space taken out: what the
-    counter profiles are valid for (a reworded comment does not make a profile stale, a changed statement does)"""
+    """sha256 over the sources the profiled kernels (basic front and back end) are compiled from, with comments and
+    white space taken out: what the counter profile is valid for (a reworded comment does not make it stale, a
+    changed statement does; the filter-bank kernels and the host code have no part in it)"""
     import hashlib
     import re
     h = hashlib.sha256()
+    names = ("peaq_frontend.hip", "peaq_backend.hip", "peaq_wave.h", "peaq_device.h", "peaq_kernels.h", "Makefile")
     for f in sorted((ROOT / "gstpeaq_amd" / "csrc").glob("*")):
-        if f.is_file():
+        if f.is_file() and f.name in names:
             text = f.read_text(errors="replace")
             if f.suffix in (".hip", ".h", ".cpp"):
                 text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
