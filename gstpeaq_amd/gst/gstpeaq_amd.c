@@ -383,17 +383,25 @@ gst_peaq_amd_sink_event (GstPad * pad, GstObject * parent, GstEvent * event)
   const gint idx = pad_index (self, pad);
   gboolean ret;
   switch (GST_EVENT_TYPE (event)) {
-    case GST_EVENT_EOS:
-      /* a sink posts EOS once ALL its pads are at EOS (gstpeaq.c:668-688) */
+    case GST_EVENT_EOS:{
+      /* a sink posts EOS once ALL its pads are at EOS (gstpeaq.c:668-688).  Under the object lock: the two pads'
+       * streaming threads get here at the same moment often enough (one process in thirty with 1024 elements), and
+       * unlocked each could write its own flag, read the other's old value and leave the posting to the other --
+       * a pipeline that never ends. */
+      gboolean both;
+      GST_OBJECT_LOCK (self);
       self->eos[idx] = TRUE;
+      both = self->eos[0] && self->eos[1];
+      GST_OBJECT_UNLOCK (self);
       ret = TRUE;
-      if (self->eos[0] && self->eos[1]) {
+      if (both) {
         GstMessage *msg = gst_message_new_eos (parent);
         gst_message_set_seqnum (msg, gst_event_get_seqnum (event));
         ret = gst_element_post_message (GST_ELEMENT (self), msg);
       }
       gst_event_unref (event);
       return ret;
+    }
     case GST_EVENT_CAPS:{
       GstCaps *caps;
       gst_event_parse_caps (event, &caps);
