@@ -515,16 +515,23 @@ __device__ __forceinline__ void fir_mfma_tail(BankLds<typename M::T>& sh, const 
 //   tile     D[16 rows][64 columns] = coef[16][32] x (32 samples x 64 window columns from bs_col_head on): per band
 //            the three exponentials' ENTER rows (re, im) and the filter's own coefficients on the block its window
 //            ENDS in -- 32 matrix instructions, written to the wave's staging rows by output;
-//   left     the filter's own coefficients on the block the window STARTS in: at most 32 taps on the vector ALU,
-//            lanes = outputs (two rows of sixteen would fill a matrix tile to a quarter);
-//   chain    lanes = outputs: V_i(t) = rot_i V_i(t-1) + enter(t) - rot_i^J enter(t - J) as a complex prefix scan
-//            over the wave (DPP row shifts + three row carries), y(t) = V_0 + V_1 + V_2 + the two edge blocks.
-//            enter(t - J) is read from the staging rows, or for the tile's first J outputs from the history
-//            (FbSignalState::bs_hist: the last J enter values per exponential, re-written after every tile).
+//   sums     a lane per (chain, segment of kBsSeg = 9 consecutive outputs), eight lanes per chain, the pair's six
+//            chains at once: d(t) = enter(t) - rot^J enter(t - J) from the staging rows (what leaves: from the history,
+//            FbSignalState::bs_hist, for the segments in front of output J -- the segments are shifted so that output
+//            J starts one), V(t) = rot V(t-1) + d(t) once with nothing carried in, a weighted DPP scan over the chain's
+//            eight segments, V(-1)'s share, then the recurrence again; the sums are written over the enter values.
+//            (First version: lanes = outputs and a wave-wide prefix scan per chain in the frame of output -1 -- 64 vector
+//            instructions per chain; bs_chain is still that, for V(-1) on a launch's first tile.)
+//   left     lanes = outputs again: the filter's own coefficients on the block the window STARTS in, at most 16 taps on
+//            the vector ALU (FbTables::bs_left_g; two rows of sixteen would fill a matrix tile to a quarter), and
+//            y(t) = V_0 + V_1 + V_2 + the two edge blocks from the rows.
 // The running sums V are carried from tile to tile in LDS (vst); the first tile of a launch computes them from the
 // history (V(-1) = sum_s rot^s enter(-1 - s): one more scan) -- so the only state is the history, which is exact:
 // rounding errors of the sums cannot travel further than a launch, and nothing is left of a sample 1456 samples
 // after it, as in the reference's delay line.
+// What a lane reads of its neighbour chain in the scan is multiplied by zero, not selected away: every value a lane can
+// reach has to be FINITE -- outputs that do not exist included (zeroed slots in bs_pair, A zeroed once per workgroup,
+// a window that ends with the signal's own blocks: fb_bank_body, row_valid).
 // ---------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) double kdouble;   // read through the scalar cache when the address is uniform
 typedef const __attribute__((address_space(4))) int kint;
