@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How far does the advanced version's default engine (split-FP16 FIR, FP32 slopes and spreading) get from the
+"""How far does the advanced version's split-FP16 engine (FP32 slopes and spreading; the default until round 4) get from the
 all-FP64 one over MANY pairs?  N batches of 4096 seeded 10 s stereo pairs through both; distribution of |dODG|
 and |dDI|.  (The ledger, tools/precision_ledger.py, covers the goldens; this is the tail.)
   python tools/precision_soak.py [batches] > profiles/r02_precision_soak.json"""
@@ -33,7 +33,7 @@ for b in range(batches):
     odg.append(f[ok, 12])
 d_odg, d_di, odg = map(np.concatenate, (d_odg, d_di, odg))
 q = lambda x, p: float(np.quantile(x, p))
-print(json.dumps({"pairs": int(len(d_odg)), "what": "advanced PEAQ, 10 s stereo seeded pairs, default engine vs all-FP64 engine",
+print(json.dumps({"pairs": int(len(d_odg)), "what": "advanced PEAQ, 10 s stereo seeded pairs, split-FP16 engine (PEAQ_FIR_F16X3) vs the all-FP64 engine (the default since round 4: block-sum form)",
                   "odg_range": [float(odg.min()), float(odg.max())],
                   "abs_dODG": {"max": float(d_odg.max()), "p999": q(d_odg, 0.999), "p99": q(d_odg, 0.99), "median": q(d_odg, 0.5)},
                   "abs_dDI": {"max": float(d_di.max()), "p999": q(d_di, 0.999), "p99": q(d_di, 0.99), "median": q(d_di, 0.5)}},
