@@ -176,6 +176,38 @@ def result_deltas(gpu_rows, cpu, advanced):
 
 
 # ----------------------------------------------------------------------------------------------
+def device_power_info(index):
+    """Best effort, never fatal: the power cap and what the board reports right now (sysfs hwmon of the amdgpu card,
+    else rocm-smi) -- with the calibration kernel's clock what tells a slow box from a slow library."""
+    import glob
+    info = {}
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        if cards:
+            h = cards[min(index, len(cards) - 1)]
+
+            def rd(name, scale):
+                try:
+                    return float(open(f"{h}/{name}").read().strip()) * scale
+                except Exception:
+                    return None
+            info = {"source": h, "power_cap_w": rd("power1_cap", 1e-6), "power_cap_max_w": rd("power1_cap_max", 1e-6),
+                    "power_now_w": rd("power1_average", 1e-6) or rd("power1_input", 1e-6),
+                    "sclk_now_mhz": rd("freq1_input", 1e-6), "temp_c": rd("temp1_input", 1e-3)}
+    except Exception:
+        pass
+    if not info.get("power_cap_w"):
+        try:
+            out = subprocess.run(["rocm-smi", "-d", str(index), "--showmaxpower", "--showpower", "--showclocks", "--json"],
+                                 capture_output=True, text=True, timeout=20).stdout
+            d = json.loads(out[out.index("{"):])
+            card = next(iter(d.values()))
+            info = {"source": "rocm-smi", "raw": {k: v for k, v in card.items() if any(t in k.lower() for t in ("power", "sclk"))}}
+        except Exception as e:
+            info = info or {"error": repr(e)[:120]}
+    return info
+
+
 def source_hash():
     """sha256 over the sources the profiled kernels (basic front and back end) are compiled from, with comments and
     white space taken out: what the counter profile is valid for (a reworded comment does not make it stale, a
@@ -242,6 +274,23 @@ def main():
                     help="skip the waves-mode pass that makes an N = 1 line comparable with N > 1 lines")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` by itself (no launcher, N > 1): become the launcher -- one process per GPU under
+    # torch.distributed.run on 127.0.0.1 with a free port -- so that the driver's N = 1 command shape also works for
+    # N = 2, 4, 8.  Under torch.distributed.run (WORLD_SIZE set) nothing changes.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        if os.environ.get("PEAQ_BENCH_LAUNCH_DRYRUN") == "1":   # tests/test_capi_host.py: the command, not the run
+            print(json.dumps({"launch": cmd}))
+            return
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+
     import numpy as np
     import torch
     import gstpeaq_amd
@@ -251,8 +300,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py --gpus {args.gpus} inside a job of WORLD_SIZE {world}: launch it as `python bench.py "
+                         f"--gpus N` (it starts its own ranks) or under torch.distributed.run --nproc-per-node N")
     # PEAQ_BENCH_DIST_BACKEND=gloo: the N > 1 path with a CPU communicator, every rank on the GPU(s) the box has
     # (RCCL refuses two ranks on one device) -- how tests/test_gpu_two_ranks.py runs two REAL ranks on a one-GPU
     # box: shards, seeds, waves, timing reduction and the gather (staged through host memory) are the production
@@ -427,7 +476,11 @@ def main():
                 "fb_ms": timing["fb_ms"], "step_ms_events": timing["total_ms"]}
 
     main_adv = bool(args.advanced)
+    # the device's clock under a fixed FP64 load before and after the timed region, and (below) while the step itself ran
+    cal0 = ctx.calibrate() if rank == 0 else None
     m = measure(main_adv, args.steps, args.warmup)
+    step_clock_mhz = ctx.last_clock_mhz()
+    cal1 = ctx.calibrate() if rank == 0 else None
     odg = m["gathered"][:, 12]
     line = None
     if rank == 0:
@@ -466,6 +519,17 @@ def main():
             "odg_nan": int(torch.isnan(odg).sum().item()),
         }
         line["per_gpu_value"] = value / world
+        nominal = cal0["max_clock_mhz"] or 2400.0
+        line["device_clock"] = {
+            "step_shader_clock_mhz": step_clock_mhz,
+            "calibration_before": cal0, "calibration_after": cal1, "nominal_mhz": nominal,
+            "power": device_power_info(local_rank),
+            "how": "step clock: workgroup 0 of every back-end launch of the last timed pass reads the shader-clock and the "
+                   "constant-rate counter around its lifetime, beside the front end of the next chunk (peaq_batch_last_clock); "
+                   "calibration: peaq_calibrate, a fixed v_fma_f64 kernel (two waves per SIMD) before and after the timed "
+                   "region; rank 0's device"}
+        # the same line at the device's nominal clock: the path is issue-bound, its time scales with 1 / clock
+        line["value_at_nominal_clock"] = value * nominal / step_clock_mhz if step_clock_mhz else None
         line["result_gather_ms"] = m["gather_ms"]           # after the timed region; 128 B per pair
         if waves_mode:
             line["wall_ms_per_step_incl_generation"] = m["wall"] / args.steps * 1e3
@@ -487,8 +551,9 @@ def main():
         try:
             ctx.set_fir_mode("f64")
             m64 = measure(True, adv_steps, 1)
+            adv_clock = ctx.last_clock_mhz()
             if rank == 0:
-                adv = {"config": wl,
+                adv = {"config": wl, "step_shader_clock_mhz": adv_clock,
                        "metric": "FFT frame-pairs/sec (advanced PEAQ: 55-band FFT model + 40-band filter bank, 5 MOVs)",
                        "value": m64["fp_all"] * adv_steps / m64["timed"], "unit": "frame-pairs/s", "steps": adv_steps,
                        "warmup": 1, "ms_per_step": m64["timed"] / adv_steps * 1e3,

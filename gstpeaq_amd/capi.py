@@ -29,6 +29,11 @@ class PeaqError(RuntimeError):
     pass
 
 
+class _Calibration(C.Structure):
+    _fields_ = [("elapsed_ms", C.c_double), ("shader_clock_mhz", C.c_double), ("fp64_tflops", C.c_double),
+                ("cycles_per_fma", C.c_double), ("max_clock_mhz", C.c_double), ("compute_units", C.c_int)]
+
+
 class _Timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("frontend_ms", C.c_float), ("frontend_launches", C.c_int),
                 ("backend_ms", C.c_float), ("backend_launches", C.c_int),
@@ -109,6 +114,8 @@ def load_library():
     L.peaq_batch_workspace_bytes.restype = C.c_size_t
     L.peaq_batch_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32]
     L.peaq_batch_last_timing.argtypes = [vp, C.POINTER(_Timing)]
+    L.peaq_calibrate.argtypes = [vp, C.c_int, C.POINTER(_Calibration)]
+    L.peaq_batch_last_clock.argtypes = [vp, dp]
     L.peaq_synth_fill.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_size_t, vp, vp, vp]
     L.peaq_debug_frontend.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp, vp, C.c_uint32, C.c_uint32,
                                       C.c_int, dp]
@@ -202,6 +209,18 @@ class Context:
         t = _Timing()
         _check(self.L.peaq_batch_last_timing(self.h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in _Timing._fields_}
+
+    def last_clock_mhz(self):
+        """shader clock while the last batch ran (peaq_batch_last_clock)"""
+        v = C.c_double(0.)
+        _check(self.L.peaq_batch_last_clock(self.h, C.byref(v)))
+        return v.value
+
+    def calibrate(self, iterations=0):
+        """peaq_calibrate: shader clock and FP64 rate of this device under a fixed FP64 load (include/peaq_amd.h)"""
+        t = _Calibration()
+        _check(self.L.peaq_calibrate(self.h, int(iterations), C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _Calibration._fields_}
 
 
 class Session:

@@ -432,6 +432,12 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
     if (f_end > n_frames) f_end = n_frames;
   }
   if (f_begin >= f_end) return;
+  const bool clk_wave = a.clk && blockIdx.x == 0 && chan == 0;   // wave-uniform
+  unsigned long long clk_s0 = 0, clk_w0 = 0;
+  if (clk_wave) {
+    clk_w0 = wall_clock64();
+    clk_s0 = __builtin_readcyclecounter();
+  }
   if (lane < kPaPad) sh.pa[chan][0][lane] = sh.pa[chan][1][lane] = 0.;
   __syncthreads();                                   // the table copy is complete
 
@@ -720,6 +726,10 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
     if (!ADV) ps->loudness_reached = loud_reached;
     ps->sig_energy = sh.energy[0];
     ps->noise_energy = sh.energy[1];
+  }
+  if (clk_wave && lane == 0) {                       // launches of one batch follow each other on one stream: one writer
+    a.clk[0] += __builtin_readcyclecounter() - clk_s0;
+    a.clk[1] += wall_clock64() - clk_w0;
   }
 }
 

@@ -397,9 +397,9 @@ struct MfmaH3 {
 
 // FP32 variant (PEAQ_FIR_F32, selectable): the mixed-precision ledger (tools/precision_ledger.py,
 // profiles/r02_precision_ledger.json) prices it at max |dODG| = 5e-8 over 39 advanced cases -- the FIR outputs
-// only enter the model as |A|^2 in 40 bands after spreading and masking.  The engine's default is the split-FP16
-// form below (fir_mfma_h3); peaq_ctx_set_fir_mode() / PEAQ_AMD_FIR select this one or the FP64 instruction
-// (the arithmetic the stage tests hold to 1e-9 of the oracle).
+// only enter the model as |A|^2 in 40 bands after spreading and masking.  The engine's default is the FP64 block-sum
+// form (bs_pair, the arithmetic the stage tests hold to 1e-9 of the oracle); peaq_ctx_set_fir_mode() / PEAQ_AMD_FIR
+// select this one or the split-FP16 form below (fir_mfma_h3).
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Adds the accumulator tiles of one run of K steps into A (LDS atomics; A was zeroed in phase 0).
@@ -434,78 +434,65 @@ struct FirSeg {
 };
 
 // The direct (folded) form for the FP64 engine's short filters: ONE row tile, bands 24 .. 39 (peaq_device.h kMfd*),
-// its 30 K steps cut into four runs (8 + 8 + 7 + 7), one per wave; every run leaves a partial sum that is added
-// into A with LDS atomics (rows 24 .. 39 are zeroed before).  Operands as described above: per K step two
-// coalesced coefficient reads (all of a run's are requested up front) and eight window reads one step ahead.
+// 30 K steps of four delays.  The work is dealt to the four waves by OUTPUT -- wave = (real or imaginary part) x (time
+// points 0 .. 31 or 32 .. 63) -- so that every element of A is one wave's own sequential sum over all K steps, written
+// with a plain store: the result does not depend on which wave gets where first, and two runs on the same input agree
+// bit for bit (the reference's sums are sequential, fbearmodel.c:399-435).  Until round 5 the K steps were cut into
+// four runs whose partial sums met in A through LDS atomics, in whatever order the waves arrived.  Per K step a wave
+// now needs one coefficient (its part's), four window reads and two additions for its two matrix instructions;
+// the coefficients are requested eight steps ahead.
 template <typename M>
 __device__ __forceinline__ void fir_mfma_tail(BankLds<typename M::T>& sh, const typename M::T* __restrict__ mf_re,
                                               const typename M::T* __restrict__ mf_im, int wv, int lane) {
   typedef typename M::T T;
   typedef typename M::Acc Acc;
-  static_assert(8 + 8 + 7 + 7 == kMfdSteps, "split of the K steps over the four waves");
   const int j = lane & 15, kk = lane >> 4;
-  const int g = wv < 2 ? 8 * wv : 16 + 7 * (wv - 2);
-  const int n = wv < 2 ? 8 : 7;
+  const bool imag = wv & 1;                            // wave-uniform
+  const int q0 = 2 * (wv >> 1);                        // the wave's two time tiles: q0, q0 + 1
   const Acc zero = {0, 0, 0, 0};
-  Acc ar0 = zero, ar1 = zero, ar2 = zero, ar3 = zero, ai0 = zero, ai1 = zero, ai2 = zero, ai3 = zero;
-  // (the addresses are hidden from the compiler: the coefficients are the same in every tile, and hoisted out of
-  // the tile loop their 32 registers -- with the other phases' -- end up in scratch)
-  const T* cr = mf_re + (size_t)g * 64 + lane;
-  const T* ci = mf_im + (size_t)g * 64 + lane;
-  asm volatile("" : "+v"(cr), "+v"(ci));
-  T hr[8], hi[8];
+  Acc a0 = zero, a1 = zero;
+  // (the address is hidden from the compiler: the coefficients are the same in every tile, and hoisted out of the
+  // tile loop their registers -- with the other phases' -- end up in scratch)
+  const T* cp = (imag ? mf_im : mf_re) + lane;
+  asm volatile("" : "+v"(cp));
+  constexpr int kAhead = 8;
+  T h[kAhead];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int qq = q < n ? q : n - 1;                // (wave-uniform; the eighth load of a seven-step run repeats the seventh)
-    hr[q] = cr[64 * qq];
-    hi[q] = ci[64 * qq];
-  }
-  const int d = kMfdD0 + 4 * g + kk;                 // this lane's delay in the first K step
-  int u1 = kFbRing - d;                              // window coordinate of x[-d] at t = 0 ...
-  int u2 = d - 2;                                    // ... and of its mirror x[-(1458 - d)]
-  T bx[4], by[4];
-  auto fetch = [&](T (&x)[4], T (&y)[4]) {
-    const T* p1 = sh.win.v + win_off(u1) + j;        // time points j, 16 + j, 32 + j, 48 + j
-    const T* p2 = sh.win.v + win_off(u2) + j;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      x[q] = lds_rd(p1 + 16 * q);
-      y[q] = lds_rd(p2 + 16 * q);
-    }
+  for (int q = 0; q < kAhead; ++q) h[q] = cp[64 * q];
+  int u1 = kFbRing - (kMfdD0 + kk);                    // window coordinate of x[-d] at t = 0, d = this lane's delay in step 0 ...
+  int u2 = kMfdD0 + kk - 2;                            // ... and of its mirror x[-(1458 - d)]
+  auto fetch = [&](T (&x)[2], T (&y)[2]) {
+    const T* p1 = sh.win.v + win_off(u1) + j + 16 * q0;   // time points 16 q0 + j, 16 (q0 + 1) + j
+    const T* p2 = sh.win.v + win_off(u2) + j + 16 * q0;
+    x[0] = lds_rd(p1);
+    x[1] = lds_rd(p1 + 16);
+    y[0] = lds_rd(p2);
+    y[1] = lds_rd(p2 + 16);
   };
+  T bx[2], by[2];
   fetch(bx, by);
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    if (s < n) {
-      T nx[4], ny[4];
-      u1 -= 4;
-      u2 += 4;
-      fetch(nx, ny);                                 // (one step beyond the run's last: inside the window, unused)
-      __builtin_amdgcn_sched_barrier(0);             // keep the reads up here (the scheduler sinks them to their use)
-      ar0 = M::mma(hr[s], bx[0] + by[0], ar0);
-      ai0 = M::mma(hi[s], bx[0] - by[0], ai0);
-      ar1 = M::mma(hr[s], bx[1] + by[1], ar1);
-      ai1 = M::mma(hi[s], bx[1] - by[1], ai1);
-      ar2 = M::mma(hr[s], bx[2] + by[2], ar2);
-      ai2 = M::mma(hi[s], bx[2] - by[2], ai2);
-      ar3 = M::mma(hr[s], bx[3] + by[3], ar3);
-      ai3 = M::mma(hi[s], bx[3] - by[3], ai3);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        bx[q] = nx[q];
-        by[q] = ny[q];
-      }
-    }
+  for (int s = 0; s < kMfdSteps; ++s) {
+    T nx[2], ny[2];
+    u1 -= 4;
+    u2 += 4;
+    fetch(nx, ny);                                     // (one step beyond the last: inside the window, unused)
+    const T c = h[s % kAhead];
+    if (s + kAhead < kMfdSteps) h[s % kAhead] = cp[64 * (s + kAhead)];
+    __builtin_amdgcn_sched_barrier(0);                 // keep the reads up here (the scheduler sinks them to their use)
+    a0 = M::mma(c, imag ? bx[0] - by[0] : bx[0] + by[0], a0);
+    a1 = M::mma(c, imag ? bx[1] - by[1] : bx[1] + by[1], a1);
+    bx[0] = nx[0];
+    bx[1] = nx[1];
+    by[0] = ny[0];
+    by[1] = ny[1];
   }
-  const Acc accr[4] = {ar0, ar1, ar2, ar3}, acci[4] = {ai0, ai1, ai2, ai3};
+  double (*A)[kACols] = imag ? sh.a.im : sh.a.re;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int b = kMfdBand0 + M::row(kk, i);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      atomicAdd(&sh.a.re[b][16 * nt + j], (double)accr[nt][i]);
-      atomicAdd(&sh.a.im[b][16 * nt + j], (double)acci[nt][i]);
-    }
+    A[b][16 * q0 + j] = (double)a0[i];
+    A[b][16 * (q0 + 1) + j] = (double)a1[i];
   }
 }
 
@@ -1284,16 +1271,8 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         }
 #undef PEAQ_Y_KEEP
       }
-      // Rows 24 .. 39 of A, which the direct tile adds into, lie inside the staging rows of waves 1 (re) and 3 (im):
-      // each zeroes them once it is through with its own pairs, in front of the barrier, so that no second barrier
-      // has to stand between the results below and the direct tile.
-      static_assert(kStWave <= kMfdBand0 * kACols && 2 * kStWave <= kFbBands * kACols && (kMfdBand0 * kACols) % 2 == 0 &&
-                        ((kFbBands - kMfdBand0) * kACols) % 2 == 0,
-                    "waves 0 and 2 stay below row 24 of their half, waves 1 and 3 inside it");
-      if (wv & 1) {
-        double2* z = reinterpret_cast<double2*>(wv == 1 ? &sh.a.re[kMfdBand0][0] : &sh.a.im[kMfdBand0][0]);
-        for (int i = lane; i < (kFbBands - kMfdBand0) * kACols / 2; i += 64) z[i] = make_double2(0., 0.);
-      }
+      // (rows 24 .. 39 of A, which the direct tile writes, lie inside the staging rows of waves 1 and 3: the barrier
+      // below stands between their last use and those stores)
       FB_MARK(13);
       __syncthreads();                                               // every wave is done with its staging rows
 #pragma unroll

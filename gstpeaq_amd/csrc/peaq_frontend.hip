@@ -596,19 +596,15 @@ void frontend_kernel(FrontendArgs a) {
   // (advanced version: of the test signal only the weighted spectrum is used -- noise in bands and EHS,
   // process_fft_block_advanced gstpeaq.c:924-959 -- so its wave goes straight to the barrier)
   if (!kAdvanced || sig == 0) {
-    // lane owns bands 2*lane and 2*lane+1
+    // lane owns bands 2 lane and 2 lane + 1
     const double* pw = unit + kOffPw;
-    // upward-spreading accumulators, split by target parity: up[par][idx] = E2up[2 idx + par].
-    // All lanes of one atomic hit the same parity at consecutive idx (8-byte stride): no bank conflicts.
-    double* e2up = scratch;                            // [2][128]
-    for (int i = lane; i < 256; i += 64) e2up[i] = 0.;
     constexpr int kZeroSlot = kOffScratch + 400 - kOffPw;   // a free word of the scratch area, as an index into Pw
     if (lane == 0) scratch[400] = 0.;
     wave_lds_fence();
     // Band sums with a balanced assignment -- lane L adds up band L (narrow) and band NB-1-L (wide):
     // the longest loop is ~27 bins instead of the ~50 of two adjacent top bands -- handed over to
     // the two-adjacent-bands layout of everything that follows through LDS.
-    double* ppx = scratch + 256;                       // [NB]
+    double* ppx = scratch + 256;                       // [128]
     // ... and the per-band constants of the spreading phase, requested before the band sums run
     const int b0 = 2 * lane;
     double c_noise[2], c_lnauc[2], c_gil[2];
@@ -626,7 +622,17 @@ void frontend_kernel(FrontendArgs a) {
     }
     wave_lds_fence();
     FE_MARK(3);                                        // band grouping
-    double ene[2], ae[2];
+    // Upward spreading, Kabal (27): E2[j] += Ene[i] a_i^(j-i) for j > i, a_i = aUCEe[i] -- the reference's O(B^2) loop
+    // (fftearmodel.c:657-667).  Every band's contributions are a geometric sequence along the target bands; they used
+    // to be scattered into LDS with one atomic per step (an LDS atomic costs this kernel five FP64 instructions'
+    // worth of time, profiles/r05_ab_basic.txt).  Now the ACCUMULATORS travel instead: the pair of sums for the bands
+    // of lane M sits in lane M - k while the sources add what they send k lanes up, and moves one lane up (two DPP
+    // moves per double, zeros entering at lane 0) after every step, k = kLanes .. 1 -- so it arrives home complete,
+    // and sums for bands that do not exist leave at the top.  Walking k DOWN means walking each source's sequence
+    // from its far end: u = Ene[2L] a^(2k), v = Ene[2L+1] a'^(2k-1) start at k = kLanes from one exponential each
+    // and go back two bands per step with 1 / a^2; what a lane adds per step is (u + v, a u + a' v).
+    constexpr int kLanes = (NB - 1) / 2;               // the farthest lane a band reaches: band 0 -> band NB - 1
+    double ene[2], ae[2], far[2], back2[2];            // far: the source's term 2 kLanes (2 kLanes - 1) bands up; back2 = a^-2
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int b = b0 + s;
@@ -642,28 +648,33 @@ void frontend_kernel(FrontendArgs a) {
         const double g_iu = div_fast(1. - exp_fast((double)(NB - b) * ln_a), 1. - a_uce);
         ae[s] = t2;
         ene[s] = exp_fast(0.4 * (ln_pp - FE_LOG(c_gil[s] + g_iu - 1., ltab)));
+        far[s] = ene[s] * exp_fast((0.4 * (2 * kLanes - s)) * ln_a);
+        back2[s] = div_fast(1., t2 * t2);
       } else {
         ae[s] = 0.;
         ene[s] = 0.;
+        far[s] = 0.;
+        back2[s] = 0.;
       }
     }
-    wave_lds_fence();
     FE_MARK(4);                                        // logarithms / exponentials per band
-    // upward spreading, Kabal (27): E2[j] += Ene[i] * aUCEe[i]^(j-i) for j > i.
-    // The lane's two bands 2 lane and 2 lane + 1 reach target 2 lane + s after s and s - 1 steps:
-    // their contributions are added in registers and leave as ONE LDS atomic per step; the
-    // targets of one instruction are distinct (consecutive slots of one parity), no contention.
+    double up0 = 0., up1 = 0.;                         // E2up of the bands 2 (lane + k), 2 (lane + k) + 1 while in flight
     {
-      double r0 = ene[0] * ae[0], r1 = ene[1];         // r0 = Ene[2 lane] a^s, r1 = Ene[2 lane + 1] a^(s-1)
-      atomicAdd(&e2up[128 + lane], r0);                // s = 1: target 2 lane + 1, band 2 lane alone
-#pragma unroll 12
-      for (int s = 2; s <= NB; ++s) {
-        r0 *= ae[0];
-        r1 *= ae[1];
-        atomicAdd(&e2up[128 * (s & 1) + lane + (s >> 1)], r0 + r1);
+      double u = far[0], v = far[1];
+#pragma unroll 9
+      for (int k = kLanes; k >= 1; --k) {
+        up0 += u;
+        up0 += v;
+        up1 = fma(ae[0], u, up1);
+        up1 = fma(ae[1], v, up1);
+        up0 = lane_below(up0);
+        up1 = lane_below(up1);
+        u *= back2[0];
+        v *= back2[1];
       }
+      up1 = fma(ae[0], ene[0], up1);                   // band 2 lane to its own neighbour 2 lane + 1
     }
-    FE_MARK(5);                                        // upward spreading loop
+    FE_MARK(5);                                        // upward spreading
     // downward spreading, Kabal (28): E2[i-1] = aLe E2[i] + Ene[i-1]  (suffix scan)
     double dn0, dn1;
     {
@@ -673,13 +684,12 @@ void frontend_kernel(FrontendArgs a) {
       dn0 = v;
       dn1 = ene[1] + al * nxt;
     }
-    wave_lds_fence();
     // (25): the excitation is E2^(1/0.4) / normalisation; the record carries E2^(1/4), from which the back
     // end gets E and E^0.3 by multiplications (excitation_from_root, peaq_device.h)
     double root[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const double e2 = (s ? dn1 : dn0) + e2up[128 * s + lane];   // band 2 lane + s
+      const double e2 = (s ? dn1 : dn0) + (s ? up1 : up0);   // band 2 lane + s
       root[s] = b0 + s < NB ? sqrt_pos(sqrt_pos(e2)) : 0.;
     }
     if (b0 < kBandStride)
@@ -971,7 +981,10 @@ hipError_t launch_frontend(int bands, const FrontendArgs& a, unsigned n_pairs, h
     const unsigned long long t_max = (unsigned long long)n_pairs * a.frames_per_launch - 1;
     if (err && t_max >= ((1ull << 32) + err - 1) / err) return hipErrorInvalidValue;
   }
-  const size_t lds = kLdsDoubles * sizeof(double);
+#ifndef PEAQ_FE_LDS_PAD
+#define PEAQ_FE_LDS_PAD 0                    // occupancy experiments (VARIANT builds): LDS bytes a workgroup claims on top
+#endif
+  const size_t lds = kLdsDoubles * sizeof(double) + PEAQ_FE_LDS_PAD;
   if (bands == 109)
     hipLaunchKernelGGL(frontend_kernel<109>, dim3(grid), dim3(128), lds, stream, args);
   else if (bands == 55)

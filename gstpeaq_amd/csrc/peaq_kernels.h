@@ -66,6 +66,9 @@ struct BackendArgs {
   const uint32_t* pair_slot;    // state index of pair p (nullptr: p)
   double* debug;                // basic version only: [pair][frame - frame0][channel][kDbgDoubles], or nullptr
   Settings cfg;                 // floor_steps
+  // batch launches only (nullptr otherwise): workgroup 0 adds the shader-clock ticks and the constant-rate ticks of
+  // its own lifetime to clk[0], clk[1] -- the clock the device held while the step ran (peaq_batch_last_clock)
+  unsigned long long* clk;
 };
 hipError_t launch_backend(const BackendArgs& a, unsigned n_pairs, hipStream_t stream);
 

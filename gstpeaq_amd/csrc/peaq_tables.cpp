@@ -370,9 +370,8 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
   }
   for (int k = 0; k < 6; ++k) {
     const double c = std::cos(kPi * (k - 5.0) / 12.0);
-    fb.back_mask[k] = c * c * 0.9761 / 6.0;
-    if (std::fabs(fb.back_mask[k] - kBackMask[k]) > 4e-17 * kBackMask[k]) std::abort();   // peaq_device.h (a last-bit difference
-  }                                                                                        // of another libm is as good)
+    fb.back_mask[k] = c * c * 0.9761 / 6.0;     // what this host's libm gives; the kernel's compile-time copies
+  }                                              // (kBackMask, peaq_device.h) are compared in fb_tables_selfcheck()
   fill_common_bands(t, fc, kFbFrame, 1.26539, 0.004, 0.020);  // fbearmodel.c:171-177
   t.delta_z = 0.0;
 }
@@ -447,6 +446,11 @@ double fb_tables_selfcheck() {
     x[u] = (double)(int64_t)(st >> 11) / 4503599627370496.0 - 1.0 + 0.5 * std::sin(0.013 * u);
   }
   double worst = 0.;
+  // the backward-masking taps the kernel holds as compile-time constants against this host's evaluation of
+  // fbearmodel.c:182-185: another libm may differ in the last bit (1.1e-16 .. 2.2e-16 relative), nothing more
+  for (int k = 0; k < 6; ++k) worst = std::max(worst, std::fabs(fb.back_mask[k] - kBackMask[k]) / kBackMask[k]);
+  if (worst > 2.5e-16) return 1.;
+  worst = 0.;
   for (int b = 0; b < kFbBands; ++b) {
     const int half = fb.flen[b] / 2, off = fb.coef_off[b];
     // the reference's sum: taps n = 1 .. N - 1 at delays D + n, i.e. window samples 727 + N/2 - n + 32 t

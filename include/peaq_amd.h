@@ -242,12 +242,33 @@ typedef struct {
   int   fb_launches;
 } peaq_batch_timing;
 int peaq_batch_last_timing (peaq_ctx *ctx, peaq_batch_timing *out);
+/* The shader clock (MHz) the device held while the last batch ran: one workgroup of every back-end launch reads the
+ * shader-clock counter and the constant-rate counter around its own lifetime -- beside the front end of the next chunk,
+ * i.e. under the step's own load; 0 before the first batch.  With peaq_calibrate() what lets a throughput number be
+ * read as "this library at this clock". */
+int peaq_batch_last_clock (peaq_ctx *ctx, double *shader_clock_mhz);
 
 /* One whole pair from HOST memory (interleaved F32, n samples per channel each): upload + the batch path
  * with one pair + result.  For callers that hold both signals completely (gstpeaq_amd/cli/peaq.c); same
  * framing, flush and results as a session fed with the same samples (gstpeaq.c:596-611, 716-745). */
 int peaq_run_pair (peaq_ctx *ctx, int advanced, int channels, double playback_level_db,
                    const float *ref, size_t n_ref, const float *test, size_t n_test, peaq_result *out);
+
+/* ---- device calibration (measurement support, bench.py) -----------------------
+ * Runs a fixed FP64 multiply-add kernel (two waves per SIMD, eight independent chains each; `iterations` x 64
+ * multiply-adds per wave, <= 0: about 5 ms) on the context's device and reports the shader clock the device held
+ * under that load and the FP64 rate it gave.  MI355X clocks to its power budget, and this path's kernels are
+ * FP64-dense: the same library differs by several per cent from box to box.  bench.py calls this before and after
+ * its timed region so that a throughput line carries the clock it was measured at. */
+typedef struct {
+  double elapsed_ms;          /* HIP events around the kernel */
+  double shader_clock_mhz;    /* s_memtime ticks / constant-rate wall-clock ticks, mean over all waves */
+  double fp64_tflops;         /* 2 x multiply-adds issued / elapsed */
+  double cycles_per_fma;      /* shader cycles per v_fma_f64 and wave (two waves share a SIMD: 8 = the pipe's 4) */
+  double max_clock_mhz;       /* hipDeviceProp_t::clockRate */
+  int    compute_units;
+} peaq_calibration;
+int peaq_calibrate (peaq_ctx *ctx, int iterations, peaq_calibration *out);
 
 /* ---- synthetic workload (include/peaq_synth.h on the device) -------------
  * Fills d_ref/d_test [n_pairs][pair_stride][channels] with the seeded pairs

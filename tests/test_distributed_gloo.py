@@ -57,3 +57,24 @@ def test_two_ranks_gather_in_pair_order(tmp_path, n_total):
         got = np.load(tmp_path / f"rank{r}.npy")
         assert got.shape == single.shape
         np.testing.assert_array_equal(got, single)
+
+
+def test_bench_gpus_n_becomes_its_own_launcher():
+    """`python bench.py --gpus 4` with no WORLD_SIZE around it re-executes itself under torch.distributed.run with
+    one process per GPU on 127.0.0.1 (checked here as the command it would exec; the run itself is
+    tests/test_gpu_two_ranks.py::test_bench_gpus_2_launches_its_own_ranks on the GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["PEAQ_BENCH_LAUNCH_DRYRUN"] = "1"
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4", "--steps", "2"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    cmd = json.loads(p.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 1024
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")

@@ -101,7 +101,7 @@ def test_one_minute_stream(advanced, fir_mode):
 
 def test_many_short_pairs_advanced_chunking(fir_mode):
     """8192 stereo pairs of 2 s: so many signals that the filter-bank path has to shrink its chunk
-    (rows of high-passed samples are budgeted, peaq_capi.hip fb_blocks_per_chunk); results must not
+    (rows of high-passed samples are budgeted, peaq_batch.hip fb_blocks_per_chunk); results must not
     depend on it -- the same seeds in a small batch (one chunk) give the same numbers"""
     import torch
     import gstpeaq_amd

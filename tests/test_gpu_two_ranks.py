@@ -56,3 +56,19 @@ def test_two_ranks_on_one_gpu_equal_one_process(tmp_path):
     # 2 s pairs: 93 frame pairs each, both lines
     assert cfg["frame_pairs_per_pair"] == line1["config"]["frame_pairs_per_pair"] == 93
     assert line1["odg_mean"] == pytest.approx(line2["odg_mean"], abs=1e-12)
+
+
+def test_bench_gpus_2_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command) starts its own
+    two ranks under torch.distributed.run and prints the N = 2 line; same records as the torchrun-launched job."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (there is no CPU fallback in the product)")
+    dump = tmp_path / "self.npy"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PEAQ_BENCH_DIST_BACKEND="gloo", PEAQ_BENCH_DUMP_RESULTS=str(dump), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    line = run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--pairs", "96", "--no-cpu-baseline"] + COMMON, env)
+    assert line["n_gpus"] == 2 and line["config"]["total_pairs"] == 192
+    assert line["config"]["result_gather"] == "gloo all_gather over 2 rank(s)"
+    a = np.load(dump)
+    assert a.shape == (192, 16) and len(np.unique(a[:, 12])) > 150 and line["odg_nan"] == 0

@@ -2,9 +2,13 @@
 cross-compiles for gfx950 without a GPU).  DESIGN.md 3: a SIMD's 512 registers per lane must hold
   * three waves of the front end or of the pattern back end in any mix (<= 170 each, no scratch in the
     front end), and
-  * two waves of the filter-bank kernel of the default engine PLUS one of the high-pass kernel, whose walk
-    over the next launch's samples runs beside the bank (with 212 + 102 registers the advanced pass was 55 ms
-    longer: the bank waited for the high-pass filter)."""
+  * the filter bank of the DEFAULT engine, fb_bank_kernel<MfmaF64>: two waves per SIMD (<= 256 registers each, two
+    workgroups' LDS per CU) with nothing spilled to scratch -- it sits at the edge of that budget, and one more
+    live register would turn into scratch traffic inside the tile loop without any other sign.  Two of its waves
+    fill a SIMD, so the high-pass walk of the next launch shares a SIMD with ONE bank wave at a time (it gets
+    its slots as bank workgroups retire): bank + walk <= 512, and
+  * for the opt-in split-FP16 engine (fb_bank_kernel_h3) two bank waves PLUS one wave of the walk per SIMD (with
+    212 + 102 registers that engine's pass was 55 ms longer: the bank waited for the high-pass filter)."""
 import re
 import shutil
 import subprocess
@@ -30,7 +34,8 @@ def kernel_metadata(source, tmp_path):
         if m:
             name = m.group(1)
             meta[name] = {}
-        m = re.match(r"\s+\.(vgpr_count|vgpr_spill_count|private_segment_fixed_size|group_segment_fixed_size):\s+(\d+)", line)
+        m = re.match(r"\s+\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|agpr_count|private_segment_fixed_size|"
+                     r"group_segment_fixed_size):\s+(\d+)", line)
         if m and name:
             meta[name][m.group(1)] = int(m.group(2))
     return meta
@@ -41,9 +46,24 @@ def find(meta, fragment):
     return v
 
 
-def test_filter_bank_leaves_room_for_the_high_pass_walk(tmp_path):
-    meta = kernel_metadata("peaq_fb.hip", tmp_path)
-    bank, hp = find(meta, "fb_bank_kernel_h3"), find(meta, "fb_hp_kernel")
+@pytest.fixture(scope="module")
+def fb_meta(tmp_path_factory):
+    return kernel_metadata("peaq_fb.hip", tmp_path_factory.mktemp("fb"))
+
+
+def test_default_fp64_filter_bank_fits_two_waves_per_simd_without_scratch(fb_meta):
+    bank, hp = find(fb_meta, "fb_bank_kernelINS_7MfmaF64E"), find(fb_meta, "fb_hp_kernel")
+    assert bank["vgpr_count"] + bank.get("agpr_count", 0) <= 256, bank      # two waves per SIMD
+    assert bank["vgpr_spill_count"] == 0 and bank["private_segment_fixed_size"] == 0, bank   # nothing in scratch
+    assert bank["sgpr_spill_count"] <= 32, bank      # scalar spills go to lanes of a vector register (28 today)
+    assert 2 * bank["group_segment_fixed_size"] <= 160 * 1024, bank         # two workgroups per CU
+    # what is true for bank + walk: one wave of each on a SIMD, never two bank waves and a walk wave
+    assert hp["vgpr_spill_count"] == 0 and hp["private_segment_fixed_size"] == 0, hp
+    assert bank["vgpr_count"] + hp["vgpr_count"] <= 512, (bank, hp)
+
+
+def test_opt_in_f16x3_filter_bank_leaves_room_for_the_high_pass_walk(fb_meta):
+    bank, hp = find(fb_meta, "fb_bank_kernel_h3"), find(fb_meta, "fb_hp_kernel")
     assert bank["vgpr_spill_count"] == 0 and hp["vgpr_spill_count"] == 0
     assert 2 * bank["vgpr_count"] + hp["vgpr_count"] <= 512, (bank, hp)
     assert 2 * bank["group_segment_fixed_size"] <= 160 * 1024          # two workgroups per CU
