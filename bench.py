@@ -519,7 +519,7 @@ def main():
             "odg_nan": int(torch.isnan(odg).sum().item()),
         }
         line["per_gpu_value"] = value / world
-        nominal = cal0["max_clock_mhz"] or 2400.0
+        nominal = (cal0 or {}).get("max_clock_mhz") or 2400.0
         line["device_clock"] = {
             "step_shader_clock_mhz": step_clock_mhz,
             "calibration_before": cal0, "calibration_after": cal1, "nominal_mhz": nominal,

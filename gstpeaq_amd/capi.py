@@ -114,8 +114,9 @@ def load_library():
     L.peaq_batch_workspace_bytes.restype = C.c_size_t
     L.peaq_batch_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32]
     L.peaq_batch_last_timing.argtypes = [vp, C.POINTER(_Timing)]
-    L.peaq_calibrate.argtypes = [vp, C.c_int, C.POINTER(_Calibration)]
-    L.peaq_batch_last_clock.argtypes = [vp, dp]
+    if hasattr(L, "peaq_calibrate"):                 # (A/B runs load older variant libraries through PEAQ_AMD_LIB)
+        L.peaq_calibrate.argtypes = [vp, C.c_int, C.POINTER(_Calibration)]
+        L.peaq_batch_last_clock.argtypes = [vp, dp]
     L.peaq_synth_fill.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_size_t, vp, vp, vp]
     L.peaq_debug_frontend.argtypes = [vp, C.c_int, C.c_int, C.c_double, vp, vp, C.c_uint32, C.c_uint32,
                                       C.c_int, dp]
@@ -212,12 +213,16 @@ class Context:
 
     def last_clock_mhz(self):
         """shader clock while the last batch ran (peaq_batch_last_clock)"""
+        if not hasattr(self.L, "peaq_batch_last_clock"):
+            return 0.0
         v = C.c_double(0.)
         _check(self.L.peaq_batch_last_clock(self.h, C.byref(v)))
         return v.value
 
     def calibrate(self, iterations=0):
         """peaq_calibrate: shader clock and FP64 rate of this device under a fixed FP64 load (include/peaq_amd.h)"""
+        if not hasattr(self.L, "peaq_calibrate"):
+            return None
         t = _Calibration()
         _check(self.L.peaq_calibrate(self.h, int(iterations), C.byref(t)))
         return {k: getattr(t, k) for k, _ in _Calibration._fields_}

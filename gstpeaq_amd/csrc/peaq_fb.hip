@@ -459,33 +459,43 @@ __device__ __forceinline__ void fir_mfma_tail(BankLds<typename M::T>& sh, const 
   T h[kAhead];
 #pragma unroll
   for (int q = 0; q < kAhead; ++q) h[q] = cp[64 * q];
-  int u1 = kFbRing - (kMfdD0 + kk);                    // window coordinate of x[-d] at t = 0, d = this lane's delay in step 0 ...
-  int u2 = kMfdD0 + kk - 2;                            // ... and of its mirror x[-(1458 - d)]
-  auto fetch = [&](T (&x)[2], T (&y)[2]) {
-    const T* p1 = sh.win.v + win_off(u1) + j + 16 * q0;   // time points 16 q0 + j, 16 (q0 + 1) + j
-    const T* p2 = sh.win.v + win_off(u2) + j + 16 * q0;
-    x[0] = lds_rd(p1);
-    x[1] = lds_rd(p1 + 16);
-    y[0] = lds_rd(p2);
-    y[1] = lds_rd(p2 + 16);
+  // window operands three K steps ahead of their use (a step is two matrix instructions = 128 cycles of the pipe, an
+  // LDS round trip under load takes longer): step s reads x[-d - 4 s] and its mirror x[-(1458 - d - 4 s)], d = this
+  // lane's delay in step 0, at the wave's two time tiles
+  constexpr int kDepth = 3;
+  T bx[kDepth][2], by[kDepth][2];
+  // Eight steps are one window column (32 samples): the addresses of steps k, k + 8, k + 16, k + 24 differ by one
+  // double each, so eight offsets per operand serve all thirty steps through the reads' immediate offsets (no address
+  // arithmetic inside the loop; recomputed per tile rather than kept over it -- the kernel has no registers to spare).
+  // o1[k]: x[-d - 4 k] three columns on (the delays grow, the columns fall: steps k + 8 m read at + (3 - m) doubles),
+  // o2[k]: the mirror x[-(1458 - d - 4 k)] (columns rise: + m doubles).
+  const T* o1[8];
+  const T* o2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    o1[k] = sh.win.v + win_off(kFbRing - (kMfdD0 + 4 * k) - kk) + j + 16 * q0 - 3;
+    o2[k] = sh.win.v + win_off(kMfdD0 + 4 * k - 2 + kk) + j + 16 * q0;
+  }
+  auto fetch = [&](int s, T (&x)[2], T (&y)[2]) {
+    const int k = s & 7, m = s >> 3;
+    x[0] = lds_rd(o1[k] + (3 - m));
+    x[1] = lds_rd(o1[k] + (3 - m) + 16);
+    y[0] = lds_rd(o2[k] + m);
+    y[1] = lds_rd(o2[k] + m + 16);
   };
-  T bx[2], by[2];
-  fetch(bx, by);
+#pragma unroll
+  for (int s = 0; s < kDepth; ++s) fetch(s, bx[s], by[s]);
 #pragma unroll
   for (int s = 0; s < kMfdSteps; ++s) {
-    T nx[2], ny[2];
-    u1 -= 4;
-    u2 += 4;
-    fetch(nx, ny);                                     // (one step beyond the last: inside the window, unused)
+    const int sl = s % kDepth;
+    const T o0 = imag ? bx[sl][0] - by[sl][0] : bx[sl][0] + by[sl][0];
+    const T o1 = imag ? bx[sl][1] - by[sl][1] : bx[sl][1] + by[sl][1];
+    if (s + kDepth < kMfdSteps) fetch(s + kDepth, bx[sl], by[sl]);
     const T c = h[s % kAhead];
     if (s + kAhead < kMfdSteps) h[s % kAhead] = cp[64 * (s + kAhead)];
     __builtin_amdgcn_sched_barrier(0);                 // keep the reads up here (the scheduler sinks them to their use)
-    a0 = M::mma(c, imag ? bx[0] - by[0] : bx[0] + by[0], a0);
-    a1 = M::mma(c, imag ? bx[1] - by[1] : bx[1] + by[1], a1);
-    bx[0] = nx[0];
-    bx[1] = nx[1];
-    by[0] = ny[0];
-    by[1] = ny[1];
+    a0 = M::mma(c, o0, a0);
+    a1 = M::mma(c, o1, a1);
   }
   double (*A)[kACols] = imag ? sh.a.im : sh.a.re;
 #pragma unroll
