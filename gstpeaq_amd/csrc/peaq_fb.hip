@@ -300,6 +300,29 @@ struct Window {
       v[r * kWinRow + c] = v[r * kWinRow + kTileSub + c];
     }
   }
+  // the same with all of a thread's reads in front of its writes (one LDS round trip instead of six: as a loop of
+  // read - write the compiler has to assume that a write changes what the next read returns)
+  __device__ __forceinline__ void shift_batched(int tid) {
+    constexpr int kC = kWinCols - kTileSub, kN = 32 * kC, kPer = (kN + 255) / 256;
+    static_assert(256 / kC == 5 && kN > 256 * (kPer - 1), "element e + 256 sits five rows and 256 - 5 kC columns on");
+    int r = tid / kC, c = tid - r * kC;              // element tid + 256 q: row r, column c of the kept part
+    WT tmp[kPer];
+    int off[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      off[q] = r * kWinRow + c;
+      tmp[q] = v[(q < kPer - 1 || tid + 256 * q < kN ? off[q] : 0) + kTileSub];
+      c += 256 - 5 * kC;
+      r += 5;
+      if (c >= kC) {
+        c -= kC;
+        r += 1;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kPer; ++q)
+      if (q < kPer - 1 || tid + 256 * q < kN) v[off[q]] = tmp[q];
+  }
 };
 constexpr int kWinHBlocks = 109;                    // blocks of 32 samples: window index up to 1455 + 32 * 63 + 7
 constexpr int kWinHBytes = kWinHBlocks * 80;
@@ -1061,6 +1084,69 @@ __device__ __forceinline__ void spread_up(BankLds<WT>& sh, const double (&re)[10
   }
 }
 
+// The FP64 engine's upward spreading, dealt to the waves by TARGET: wave W owns the bands j = W, W + 4, W + 8, ...
+// (j >= 1) and sums, per time point = lane, what every lower band sends there -- all sources' outputs and slopes come
+// from LDS (A, and the slope exchange cux), the ten sums stay in registers until every wave has read its sources.
+// One wave, one sequential sum per element: the result does not depend on the order in which the waves run, and two
+// runs agree bit for bit; spread_up above has the four waves add their partial sums into A with LDS atomics in
+// whatever order they arrive (kept for the reduced-precision engines).  A source's terms at the owned targets are
+// four bands apart: its tail starts at cu^r (r = 1 .. 4 bands up to the first owned target) and moves on by cu^4.
+template <int W, typename CUX>
+__device__ __forceinline__ void spread_up_owned(const double (*are)[kACols], const double (*aim)[kACols], CUX cux, int lane,
+                                                double (&acr)[10], double (&aci)[10]) {
+#pragma unroll
+  for (int n = 0; n < 10; ++n) acr[n] = aci[n] = 0.;
+  // The sources in batches of kBatch, a batch's reads issued while the batch before it is worked on (read - compute
+  // per source, every source waited for its own LDS round trip: 39 of them per tile).  A source that is one of the
+  // wave's own targets also starts that target's sum with its own output: what leaves this function is the new A.
+  constexpr int kBatch = 4, kSrc = kFbBands;         // (band 39 sends nothing, but its output starts wave 3's last sum)
+  constexpr int kBatches = (kSrc + kBatch - 1) / kBatch;
+  double c1[2][kBatch], sr[2][kBatch], si[2][kBatch];
+  auto request = [&](int g, int buf) {
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int b = g * kBatch + k < kSrc ? g * kBatch + k : kSrc - 1;
+      c1[buf][k] = b < kFbBands - 1 ? cux(b, lane) : 0.;
+      sr[buf][k] = lds_rd(&are[b][lane]);
+      si[buf][k] = lds_rd(&aim[b][lane]);
+    }
+  };
+  request(0, 0);
+#pragma unroll
+  for (int g = 0; g < kBatches; ++g) {
+    const int buf = g & 1;
+    if (g + 1 < kBatches) request(g + 1, buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);               // (the scheduler would sink the next batch's reads to their use)
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int b = g * kBatch + k;
+      if (b >= kSrc) continue;
+      if (b >= 1 && b % 4 == W) {                    // own target: its sum starts from its own output
+        const int n = (b - (W == 0 ? 4 : W)) / 4;
+        acr[n] += sr[buf][k];
+        aci[n] += si[buf][k];
+      }
+      const int j0 = b + 1 + ((W - (b + 1)) % 4 + 4) % 4;        // the first owned target above b (compile time)
+      if (j0 < kFbBands) {
+        const int r = j0 - b;
+        const double c = c1[buf][k], c2 = c * c, c4 = c2 * c2;
+        const double cr = r == 1 ? c : r == 2 ? c2 : r == 3 ? c2 * c : c4;
+        double pr = sr[buf][k] * cr, pi = si[buf][k] * cr;
+#pragma unroll
+        for (int j = j0; j < kFbBands; j += 4) {
+          const int n = (j - (W == 0 ? 4 : W)) / 4;               // slot of target j among the wave's targets
+          acr[n] += pr;
+          aci[n] += pi;
+          if (j + 4 < kFbBands) {
+            pr *= c4;
+            pi *= c4;
+          }
+        }
+      }
+    }
+  }
+}
+
 // Phase timing for tools/fb_profile.py (development builds with -DPEAQ_FB_PROFILE only): cycles between
 // consecutive marks, summed per wave role over one sampled workgroup in 16.
 #ifdef PEAQ_FB_PROFILE
@@ -1323,12 +1409,17 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
       sh.a.re[0][lane] = re[0];                      // band 0 is nobody's spreading target
       sh.a.im[0][lane] = im[0];
     }
-    __syncthreads();                                                 // ... before phase 2b adds into A
+    // The FP64 engine deals the upward spreading to the waves by target band (spread_up_owned): its waves meet after
+    // the slopes, and its window moves on after the spreading -- until then the window's first 60 columns, dead since
+    // the filters, carry the slopes from the wave that computed them to the waves that need them.
+    constexpr bool kOwned = sizeof(WT) == 8;
+    if constexpr (!kOwned) __syncthreads();                          // ... before phase 2b adds into A
     FB_MARK(3);
     // ---- the next tile's window: nobody reads this tile's any more.  Its last 45 columns become
     // the next tile's first 45 (a tile advances by 60 columns = 1920 samples); the new samples are
     // requested further down (request_next) and land in registers while the remaining phases run ----------
-    if (b0 + kTileBlocks < nb_mine) sh.win.shift(tid);
+    if constexpr (!kOwned)
+      if (b0 + kTileBlocks < nb_mine) sh.win.shift(tid);
     auto request_next = [&]() {
       if (b0 + kTileBlocks < nb_mine) {
         const size_t first = (size_t)(b0 + kTileBlocks) * kFbFrame;  // row index of the next window's u = 0
@@ -1404,13 +1495,52 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         case 2: spread_up_f32<2, WT>(sh, re, im, cuv, lane); break;
         default: spread_up_f32<3, WT>(sh, re, im, cuv, lane); break;
       }
-    } else {
+    } else if constexpr (!kOwned) {
       switch (wv) {
         case 0: spread_up<0, WT>(sh, re, im, cuv, lane); break;
         case 1: spread_up<1, WT>(sh, re, im, cuv, lane); break;
         case 2: spread_up<2, WT>(sh, re, im, cuv, lane); break;
         default: spread_up<3, WT>(sh, re, im, cuv, lane); break;
       }
+    } else {
+      // the slopes of this wave's ten bands to where every wave finds them: band b < 32 in row b of the window array,
+      // columns 0 .. 59 = time points (dead since the filters; columns 60 .. are the next tile's), bands 32 .. 39 in
+      // e1 / ex (idle until phase 4)
+      double* wcol = reinterpret_cast<double*>(sh.win.v);
+      double* xtra = &sh.e1[0][0];
+      static_assert(sizeof(sh.e1) + sizeof(sh.ex) >= 8 * 64 * sizeof(double) && kTileSub <= 60, "room for the slopes of bands 32 .. 39");
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const int b = wave_band(wv, i);                                // (wave-uniform)
+        if (b < 32) {
+          if (lane < kTileSub) wcol[b * kWinRow + lane] = (double)cuv[i];
+        } else {
+          xtra[(b - 32) * 64 + lane] = (double)cuv[i];
+        }
+      }
+      __syncthreads();                               // slopes and A are in LDS; nobody reads this tile's window any more
+      FB_MARK(4);
+      auto cux = [&](int b, int l) { return b < 32 ? lds_rd(wcol + b * kWinRow + l) : lds_rd(xtra + (b - 32) * 64 + l); };
+      double acr[10], aci[10];
+      switch (wv) {
+        case 0: spread_up_owned<0>(sh.a.re, sh.a.im, cux, lane, acr, aci); break;
+        case 1: spread_up_owned<1>(sh.a.re, sh.a.im, cux, lane, acr, aci); break;
+        case 2: spread_up_owned<2>(sh.a.re, sh.a.im, cux, lane, acr, aci); break;
+        default: spread_up_owned<3>(sh.a.re, sh.a.im, cux, lane, acr, aci); break;
+      }
+      __syncthreads();                               // every wave has read its sources: the targets may change
+      if (lane < kTileSub) {                         // (time points 60 .. 63 do not exist: their sums came from window data)
+#pragma unroll
+        for (int n = 0; n < 10; ++n) {
+          const int j = (wv == 0 ? 4 : wv) + 4 * n;
+          if (j < kFbBands) {
+            sh.a.re[j][lane] = acr[n];
+            sh.a.im[j][lane] = aci[n];
+          }
+        }
+      }
+      // the next tile's window moves into place (over the slopes' exchange area, dead since the barrier above)
+      if (b0 + kTileBlocks < nb_mine) sh.win.shift_batched(tid);
     }
     FB_MARK(6);
     __syncthreads();
@@ -1481,6 +1611,8 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     FB_MARK(10);
     // ---- phase 5: internal noise + forward masking (fbearmodel.c:385-394).  The recurrence along
     // the blocks is walked by one thread per band into LDS; then all threads write the records --------
+    // (measured in round 5: walked by the wave that carried the band through phase 4 -- ten lanes of every wave, no
+    // barrier in front -- the phase takes 1.8 k cycles instead of 1.0 k and the pass 1 % longer)
     if (tid < kFbBands) {
       const double noise = fm_noise, ac = fm_ac;
       if (nvb == kTileBlocks) {

@@ -13,8 +13,10 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch  # noqa: E402,F401
 import gstpeaq_amd  # noqa: E402
 
-PHASES = ["0 window + zero A + barrier", "1 FIR (own run of K steps)", "2 barrier after the FIR", "3 pick up bands + barrier",
-          "4 shift window, request next", "5 log/exp/slope scan (10 bands)", "6 upward spreading", "7 barrier",
+# (FP64 engine since round 5: 1 = the direct tile, dealt by output; 3 = pick-up only; 4 = slope exchange + barrier; 6 = upward spreading by
+# target band + barrier + new A + window shift -- the reduced-precision engines keep the meanings of round 4)
+PHASES = ["0 window + zero A + barrier", "1 FIR (own run of K steps / direct tile)", "2 barrier after the FIR", "3 pick up bands (+ barrier)",
+          "4 shift window, request next / slope exchange + barrier", "5 log/exp/slope scan (10 bands)", "6 upward spreading", "7 barrier",
           "8 downward spreading + barrier", "9 backward masking + barrier", "10 history + barrier",
           "11 forward masking + barrier", "12 records",
           "13 FP64 engine: block-sum form of bands 0..23 (inside 1)", "14 FP64 engine: barrier, results -> A (inside 1)", "15 records: reads and stores (12 = the rest: next window into LDS)"]
