@@ -108,6 +108,8 @@ def load_library():
     L.peaq_session_reset.argtypes = [vp]
     L.peaq_session_set_level.argtypes = [vp, C.c_double]
     L.peaq_debug_backend.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp]
+    if hasattr(L, "peaq_debug_backend_advanced"):
+        L.peaq_debug_backend_advanced.argtypes = [vp, C.c_int, C.c_int, dp, C.c_int, dp, dp, dp, dp]
     L.peaq_batch_run.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, C.c_size_t,
                                  u32p, u32p, C.c_uint32, vp, vp]
     L.peaq_run_pair.argtypes = [vp, C.c_int, C.c_int, C.c_double, fp, C.c_size_t, fp, C.c_size_t, dp]
@@ -463,3 +465,28 @@ def debug_backend(ctx, records):
     # the MOV layer's per-frame values before accumulation (include/peaq_amd.h, PEAQ_DEBUG_BACKEND_DOUBLES)
     d["mov"] = dict(zip(BACKEND_DEBUG_MOVS, np.moveaxis(out[:, :, 904:912], 2, 0)))
     return d, _result_dict(res, False)
+
+
+ADVANCED_DEBUG_BLOCK = ["rmsmoddiff", "tempwt", "noiseloud", "missing", "lindist", "loudness_ref", "loudness_test"]
+ADVANCED_DEBUG_FRAME = ["segnmr_db", "nmr_mean"]
+
+
+def debug_backend_advanced(ctx, fb_records, fft_records):
+    """Stage-level access to the advanced version's MOV layer (fresh state).
+    fb_records: np [blocks, channels, 168] (debug_filterbank); fft_records: np [frames, channels, 576] (debug_frontend
+    with 55 bands).  -> (dict name -> np [blocks, channels] for ADVANCED_DEBUG_BLOCK, dict name -> np [frames, channels]
+    for ADVANCED_DEBUG_FRAME, result dict after the last block and frame): the values of EVERY block / frame before
+    accumulation (include/peaq_amd.h, peaq_debug_backend_advanced)."""
+    fb = np.ascontiguousarray(fb_records, dtype=np.float64)
+    ff = np.ascontiguousarray(fft_records, dtype=np.float64)
+    n_blocks, channels, w = fb.shape
+    n_frames, ch2, w2 = ff.shape
+    assert w == 168 and w2 == RECORD_DOUBLES and ch2 == channels
+    ob = np.zeros((n_blocks, channels, 8))
+    of = np.zeros((n_frames, channels, 2))
+    res = np.zeros(RESULT_DOUBLES)
+    dp = C.POINTER(C.c_double)
+    _check(ctx.L.peaq_debug_backend_advanced(ctx.h, channels, n_blocks, fb.ctypes.data_as(dp), n_frames, ff.ctypes.data_as(dp),
+                                             ob.ctypes.data_as(dp), of.ctypes.data_as(dp), res.ctypes.data_as(dp)))
+    return (dict(zip(ADVANCED_DEBUG_BLOCK, np.moveaxis(ob[:, :, :7], 2, 0))),
+            dict(zip(ADVANCED_DEBUG_FRAME, np.moveaxis(of, 2, 0))), _result_dict(res, True))

@@ -652,7 +652,10 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
         route(MB_NMR, nsum, 1.);                                    // MODE_AVG_LOG
         route(MB_RELDIST, nmax > 1.41253754462275 ? 1. : 0., 1.);
       } else {
-        route(MA_SEGNMR, (10. * kInvLn10) * log_pos(nsum), 1.);     // 10 log10, MODE_AVG; nsum > 0 (floored bands)
+        const double seg = (10. * kInvLn10) * log_pos(nsum);        // 10 log10, MODE_AVG; nsum > 0 (floored bands)
+        route(MA_SEGNMR, seg, 1.);
+        if (DBG && lane == 0)
+          a.debug[((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels + chan) * kDbgDoubles + kDbgMov + 3] = seg;
       }
     }
     // ---- error harmonic structure (movs.c:1374-1381,1442) ------------------------------
@@ -739,6 +742,8 @@ hipError_t launch_backend(const BackendArgs& a, unsigned n_pairs, hipStream_t st
   PEAQ_DEV_SPIN_INSTEAD_OF_BACKEND(a, block, stream)
   if (!a.advanced && a.debug)
     hipLaunchKernelGGL((backend_kernel<109, false, true>), dim3(n_pairs), block, 0, stream, a);
+  else if (a.debug)
+    hipLaunchKernelGGL((backend_kernel<55, true, true>), dim3(n_pairs), block, 0, stream, a);
   else if (!a.advanced)
     hipLaunchKernelGGL((backend_kernel<109, false>), dim3(n_pairs), block, 0, stream, a);
   else
@@ -756,6 +761,9 @@ struct FbBackendShared {
   int gate[2];
 };
 
+// DBG = true (peaq_debug_backend_advanced): the block's MOV values are computed for every block and written to
+// a.debug; the arithmetic is the same instantiation otherwise.
+template <bool DBG>
 __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
   __shared__ FbBackendShared sh;
   __shared__ __attribute__((aligned(16))) double sh_ltab[2 * kLogTabEntries + 2];
@@ -842,10 +850,16 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
     level_adapt<NB, SLOTS>(bl, bt, er, et, la, &sh.pa[chan][0][0], ad_ref, ad_test);
     modulation<NB, SLOTS>(bl, bt, lr, mdr, mr);
     modulation<NB, SLOTS>(bl, bt, lt, mdt, mt);
+    double* __restrict__ dbg =
+        DBG ? a.debug + ((size_t)(pair * a.blocks_per_launch + (blk - b_begin)) * channels + chan) * kDbgFbDoubles : nullptr;
     if (loud_reached == UINT_MAX) {                  // workgroup-uniform
       const double n_ref = total_loudness<NB, SLOTS>(bl, bt, er);
       const double n_test = total_loudness<NB, SLOTS>(bl, bt, et);
       if (lane == 0) sh.gate[chan] = (n_ref > 0.1 && n_test > 0.1);
+      if (DBG && lane == 0) {
+        dbg[5] = n_ref;
+        dbg[6] = n_test;
+      }
       __syncthreads();
       const int g = sh.gate[0] | (channels == 2 ? sh.gate[1] : 0);
       __syncthreads();
@@ -853,17 +867,21 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
     }
     double v0 = 0., w0 = 1.;
     bool hit = false;
-    if (blk >= 125) {                                // gstpeaq.c:988-993
+    if (DBG || blk >= 125) {                         // gstpeaq.c:988-993
       double d1, d2, wt;
       mod_difference<NB, SLOTS>(bl, bt, 1., mr, mt, mdr[1], d1, d2, wt);
       d1 *= 100. / sqrt((double)NB);                 // MODE_RMS variant, movs.c:243-244
-      if (lane == MA_RMSMOD) {
+      if (blk >= 125 && lane == MA_RMSMOD) {
         v0 = d1;
         w0 = wt;
         hit = true;
       }
+      if (DBG && lane == 0) {
+        dbg[0] = d1;
+        dbg[1] = wt;
+      }
     }
-    if (blk >= 125 && blk - 13 >= loud_reached) {    // gstpeaq.c:996-1007
+    if (DBG || (blk >= 125 && blk - 13 >= loud_reached)) {    // gstpeaq.c:996-1007
       // movs.c:551-577; SWAP_MOD_PATTS_FOR_NOISE_LOUDNESS_MOVS (shipped: 1) exchanges the modulation
       // patterns of the missing-components term ...
       const bool swap = a.cfg.swap_mod_patts != 0;   // workgroup-uniform
@@ -872,15 +890,21 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
                                                   ad_ref);
       // ... and (movs.c:679-706) takes the reference modulation twice; unadapted FB excitation
       const double ld = noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 1., 0., mr, swap ? mr : mt, ad_ref, er);
-      if (lane == MA_NLASYM) {
+      const bool open = blk >= 125 && blk - 13 >= loud_reached;
+      if (open && lane == MA_NLASYM) {
         v0 = nl;
         w0 = mc;
         hit = true;
       }
-      if (lane == MA_LINDIST) {
+      if (open && lane == MA_LINDIST) {
         v0 = ld;
         w0 = 1.;
         hit = true;
+      }
+      if (DBG && lane == 0) {
+        dbg[2] = nl;
+        dbg[3] = mc;
+        dbg[4] = ld;
       }
     }
     if (hit) acc.add(v0, w0);
@@ -907,7 +931,10 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
 
 hipError_t launch_fb_backend(const FbBackendArgs& a, unsigned n_pairs, hipStream_t stream) {
   if (n_pairs == 0) return hipSuccess;
-  hipLaunchKernelGGL(fb_backend_kernel, dim3(n_pairs), dim3(64 * a.channels), 0, stream, a);
+  if (a.debug)
+    hipLaunchKernelGGL(fb_backend_kernel<true>, dim3(n_pairs), dim3(64 * a.channels), 0, stream, a);
+  else
+    hipLaunchKernelGGL(fb_backend_kernel<false>, dim3(n_pairs), dim3(64 * a.channels), 0, stream, a);
   return hipGetLastError();
 }
 

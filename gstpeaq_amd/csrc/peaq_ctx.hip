@@ -6,6 +6,7 @@ using namespace peaq;
 static_assert(sizeof(ResultRecord) == sizeof(peaq_result), "result layouts must match");
 static_assert(kPubDoubles == PEAQ_DEBUG_RECORD_DOUBLES, "record layouts must match");
 static_assert(kDbgDoubles == PEAQ_DEBUG_BACKEND_DOUBLES, "debug layouts must match");
+static_assert(kDbgFbDoubles == PEAQ_DEBUG_ADV_BLOCK_DOUBLES, "debug layouts must match");
 
 // ---------------------------------------------------------------------------
 // errors

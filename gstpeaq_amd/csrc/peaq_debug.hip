@@ -127,6 +127,25 @@ extern "C" int peaq_debug_filterbank(peaq_ctx* c, int channels, double level_db,
   return PEAQ_OK;
 }
 
+// test-facing layout (kPub*) -> the record the kernels exchange: root = (E norm)^(1/10); the E^0.3 vector of the
+// input is implied by E (the back end derives both from the root)
+static hipError_t upload_public_records(int bands, int channels, int n_frames, const double* host_records, void* d_recs) {
+  BandTables t;
+  build_fft_band_tables(bands, t);
+  std::vector<double> h_rec((size_t)n_frames * channels * kRecDoubles, 0.);
+  for (size_t r = 0; r < (size_t)n_frames * channels; ++r) {
+    const double* in = host_records + r * kPubDoubles;
+    double* out = h_rec.data() + r * kRecDoubles;
+    for (int b = 0; b < bands; ++b) {
+      out[kRecRootRef + b] = std::pow(in[kPubUnsmRef + b] / t.inv_spread_norm[b], 0.1);
+      out[kRecRootTest + b] = std::pow(in[kPubUnsmTest + b] / t.inv_spread_norm[b], 0.1);
+    }
+    for (int b = 0; b < kBandStride; ++b) out[kRecNoise + b] = in[kPubNoise + b];
+    for (int i = 0; i < kRecDoubles - kRecScalars; ++i) out[kRecScalars + i] = in[kPubScalars + i];
+  }
+  return hipMemcpy(d_recs, h_rec.data(), h_rec.size() * sizeof(double), hipMemcpyHostToDevice);
+}
+
 extern "C" int peaq_debug_backend(peaq_ctx* c, int channels, int n_frames, const double* host_records,
                                   double* host_out, peaq_result* result) {
   if (!c || !host_records || !host_out) return fail(PEAQ_ERR_ARG, "peaq_debug_backend: NULL argument");
@@ -140,24 +159,7 @@ extern "C" int peaq_debug_backend(peaq_ctx* c, int channels, int n_frames, const
   HIP_TRY(dbg.reserve(dbg_bytes));
   HIP_TRY(st.reserve(sizeof(PairState)));
   HIP_TRY(res.reserve(sizeof(ResultRecord)));
-  {
-    // test-facing layout -> the record the kernels exchange: root = (E norm)^(1/10); the E^0.3 vector of the
-    // input is implied by E (the back end derives both from the root)
-    BandTables t;
-    build_fft_band_tables(109, t);
-    std::vector<double> h_rec((size_t)n_frames * channels * kRecDoubles, 0.);
-    for (size_t r = 0; r < (size_t)n_frames * channels; ++r) {
-      const double* in = host_records + r * kPubDoubles;
-      double* out = h_rec.data() + r * kRecDoubles;
-      for (int b = 0; b < 109; ++b) {
-        out[kRecRootRef + b] = std::pow(in[kPubUnsmRef + b] / t.inv_spread_norm[b], 0.1);
-        out[kRecRootTest + b] = std::pow(in[kPubUnsmTest + b] / t.inv_spread_norm[b], 0.1);
-      }
-      for (int b = 0; b < kBandStride; ++b) out[kRecNoise + b] = in[kPubNoise + b];
-      for (int i = 0; i < kRecDoubles - kRecScalars; ++i) out[kRecScalars + i] = in[kPubScalars + i];
-    }
-    HIP_TRY(hipMemcpy(recs.p, h_rec.data(), rec_bytes, hipMemcpyHostToDevice));
-  }
+  HIP_TRY(upload_public_records(109, channels, n_frames, host_records, recs.p));
   HIP_TRY(hipMemset(dbg.p, 0, dbg_bytes));
   HIP_TRY(launch_state_init(st.as<PairState>(), 0, 1, nullptr));
   BackendArgs ba{};
@@ -176,6 +178,74 @@ extern "C" int peaq_debug_backend(peaq_ctx* c, int channels, int n_frames, const
   HIP_TRY(launch_finalize(st.as<PairState>(), 0, channels, 1, res.as<ResultRecord>(), nullptr, c->settings));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(host_out, dbg.p, dbg_bytes, hipMemcpyDeviceToHost));
+  if (result) HIP_TRY(hipMemcpy(result, res.p, sizeof(peaq_result), hipMemcpyDeviceToHost));
+  return PEAQ_OK;
+}
+
+// The advanced version's two back ends on their own (fresh state): the filter-bank back end over n_blocks block
+// records (from peaq_debug_filterbank) and the 55-band FFT back end over n_frames front-end records (from
+// peaq_debug_frontend with 55 bands), each in its debug instantiation -- the MOV values of EVERY block / frame
+// before accumulation -- followed by the read-out of the pair's result.
+extern "C" int peaq_debug_backend_advanced(peaq_ctx* c, int channels, int n_blocks, const double* host_fb_records,
+                                           int n_frames, const double* host_fft_records, double* out_blocks,
+                                           double* out_frames, peaq_result* result) {
+  if (!c || !host_fb_records || !host_fft_records || !out_blocks || !out_frames)
+    return fail(PEAQ_ERR_ARG, "peaq_debug_backend_advanced: NULL argument");
+  if (channels != 1 && channels != 2) return fail(PEAQ_ERR_ARG, "peaq_debug_backend_advanced: channels must be 1 or 2");
+  if (n_blocks < 1 || n_frames < 1) return fail(PEAQ_ERR_ARG, "peaq_debug_backend_advanced: n_blocks, n_frames must be >= 1");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t fbrec_bytes = (size_t)n_blocks * channels * kFbRecDoubles * sizeof(double);
+  const size_t fbdbg_bytes = (size_t)n_blocks * channels * kDbgFbDoubles * sizeof(double);
+  const size_t rec_bytes = (size_t)n_frames * channels * kRecDoubles * sizeof(double);
+  const size_t dbg_bytes = (size_t)n_frames * channels * kDbgDoubles * sizeof(double);
+  TmpBuf fbrecs, fbdbg, recs, dbg, st, res;
+  HIP_TRY(fbrecs.reserve(fbrec_bytes));
+  HIP_TRY(fbdbg.reserve(fbdbg_bytes));
+  HIP_TRY(recs.reserve(rec_bytes));
+  HIP_TRY(dbg.reserve(dbg_bytes));
+  HIP_TRY(st.reserve(sizeof(PairState)));
+  HIP_TRY(res.reserve(sizeof(ResultRecord)));
+  HIP_TRY(hipMemcpy(fbrecs.p, host_fb_records, fbrec_bytes, hipMemcpyHostToDevice));
+  HIP_TRY(upload_public_records(55, channels, n_frames, host_fft_records, recs.p));
+  HIP_TRY(hipMemset(fbdbg.p, 0, fbdbg_bytes));
+  HIP_TRY(hipMemset(dbg.p, 0, dbg_bytes));
+  HIP_TRY(launch_state_init(st.as<PairState>(), 1, 1, nullptr));
+  BackendArgs ba{};
+  ba.cfg = c->settings;
+  ba.records = recs.as<double>();
+  ba.frame0 = 0;
+  ba.frames_per_launch = n_frames;
+  ba.n_frames_uniform = n_frames;
+  ba.channels = channels;
+  ba.advanced = 1;
+  ba.bands = c->d_bands55;
+  ba.common = c->d_common;
+  ba.state = st.as<PairState>();
+  ba.debug = dbg.as<double>();
+  HIP_TRY(launch_backend(ba, 1, nullptr));
+  FbBackendArgs fbk{};
+  fbk.cfg = c->settings;
+  fbk.records = fbrecs.as<double>();
+  fbk.block0 = 0;
+  fbk.blocks_per_launch = n_blocks;
+  fbk.n_blocks_uniform = n_blocks;
+  fbk.channels = channels;
+  fbk.common = c->d_common;
+  fbk.bands = c->d_bands40;
+  fbk.state = st.as<PairState>();
+  fbk.debug = fbdbg.as<double>();
+  HIP_TRY(launch_fb_backend(fbk, 1, nullptr));
+  HIP_TRY(launch_finalize(st.as<PairState>(), 1, channels, 1, res.as<ResultRecord>(), nullptr, c->settings));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out_blocks, fbdbg.p, fbdbg_bytes, hipMemcpyDeviceToHost));
+  {
+    std::vector<double> h((size_t)n_frames * channels * kDbgDoubles);
+    HIP_TRY(hipMemcpy(h.data(), dbg.p, dbg_bytes, hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < (size_t)n_frames * channels; ++r) {
+      out_frames[2 * r] = h[r * kDbgDoubles + kDbgMov + 3];       // SegmentalNMR's value (dB)
+      out_frames[2 * r + 1] = h[r * kDbgDoubles + kDbgMov + 4];   // the mean band NMR it is the logarithm of
+    }
+  }
   if (result) HIP_TRY(hipMemcpy(result, res.p, sizeof(peaq_result), hipMemcpyDeviceToHost));
   return PEAQ_OK;
 }

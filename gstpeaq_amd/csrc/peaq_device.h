@@ -247,11 +247,20 @@ constexpr int kDbgLoudnessRef  = 8 * kBandStride;   // total loudness while the 
 constexpr int kDbgLoudnessTest = 8 * kBandStride + 1;
 // the MOV layer's per-frame values BEFORE accumulation, computed for every frame in the debug instantiation
 // (the accumulators only see them when the gates of gstpeaq.c:871,880-881 are open):
-constexpr int kDbgMov          = 8 * kBandStride + 8;   // + 0 ModDiff1, 1 ModDiff2, 2 TempWt (movs.c:205-254), 3 noise
+constexpr int kDbgMov          = 8 * kBandStride + 8;   // (advanced, 55 bands: 3 = SegmentalNMR's 10 log10 of the mean, movs.c:1010-1020)
+                                                        // + 0 ModDiff1, 1 ModDiff2, 2 TempWt (movs.c:205-254), 3 noise
                                                         // loudness (:354-371), 4 mean and 5 maximum of the band NMRs
                                                         // (:971-1023); channel 0 only: 6 detection probability, 7 steps
                                                         // above threshold (:1224-1276)
 constexpr int kDbgDoubles      = 8 * kBandStride + 16;  // == PEAQ_DEBUG_BACKEND_DOUBLES
+
+// stage-level dump of the filter-bank back end (peaq_debug_backend_advanced): per (block, channel) the MOV layer's
+// values BEFORE accumulation, computed for every block in the debug instantiation (the accumulators only see them
+// when the gates of gstpeaq.c:988,996-997 are open):
+//   0 RmsModDiff (movs.c:205-254 with the RMS normalisation of :243-244)   1 its weight (TempWt, level weight 1)
+//   2 noise loudness of RmsNoiseLoudAsym (movs.c:551-577)   3 its missing-components term (the accumulator's weight)
+//   4 AvgLinDist (movs.c:679-706)   5, 6 total loudness of ref / test while the gate is closed (earmodel.c:891-907)
+constexpr int kDbgFbDoubles = 8;                      // == PEAQ_DEBUG_ADV_BLOCK_DOUBLES
 
 // filter-bank record per (pair, block, channel): unsmeared/excitation of both
 // signals + above-threshold flag

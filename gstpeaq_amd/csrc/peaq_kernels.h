@@ -136,6 +136,9 @@ struct FbBackendArgs {
   PairState* state;
   const FbPairWindow* windows;  // broker launches
   Settings cfg;                 // swap_mod_patts
+  // stage tests only (peaq_debug_backend_advanced): [pair][block - block0][channel][kDbgFbDoubles] -- the block's MOV
+  // values before accumulation, computed for EVERY block in the debug instantiation -- or nullptr
+  double* debug;
 };
 hipError_t launch_fb_backend(const FbBackendArgs& a, unsigned n_pairs, hipStream_t stream);
 

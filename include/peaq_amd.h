@@ -324,6 +324,23 @@ int peaq_debug_backend (peaq_ctx *ctx, int channels, int n_frames, const double 
  * largest output (about 4e-15).  tests/test_capi_host.py runs it on the CPU. */
 double peaq_debug_fb_tables_selfcheck (void);
 
+/* The advanced version's MOV layer on its own (fresh state): the filter-bank back end over
+ *   fb_records  [n_blocks][channels][PEAQ_DEBUG_FB_RECORD_DOUBLES]   (as peaq_debug_filterbank returns them)
+ * and the 55-band FFT back end over
+ *   fft_records [n_frames][channels][PEAQ_DEBUG_RECORD_DOUBLES]      (as peaq_debug_frontend returns them for 55 bands),
+ * every block's / frame's MOV values BEFORE accumulation -- also those the gates of gstpeaq.c:988,996-997 keep from
+ * the accumulators:
+ *   out_blocks [n_blocks][channels][PEAQ_DEBUG_ADV_BLOCK_DOUBLES] = { RmsModDiff (movs.c:205-254, RMS normalisation
+ *              :243-244), its weight, the noise loudness of RmsNoiseLoudAsym and its missing-components term
+ *              (movs.c:551-577), AvgLinDist (movs.c:679-706), total loudness of ref and test while the loudness
+ *              gate is closed (earmodel.c:891-907; 0 afterwards), pad }
+ *   out_frames [n_frames][channels][2] = { SegmentalNMR's 10 log10 of the mean band NMR (movs.c:1010-1020), that mean }
+ * and the pair's result after the last block and frame. */
+#define PEAQ_DEBUG_ADV_BLOCK_DOUBLES 8
+int peaq_debug_backend_advanced (peaq_ctx *ctx, int channels, int n_blocks, const double *fb_records,
+                                 int n_frames, const double *fft_records, double *out_blocks,
+                                 double *out_frames, peaq_result *result);
+
 #ifdef __cplusplus
 }
 #endif

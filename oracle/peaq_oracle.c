@@ -800,6 +800,12 @@ struct orc_session {
    * accumulation, whether or not the gates of gstpeaq.c:871,880-881 are open */
   double *trace;
   unsigned trace_frames;
+  /* the same for the advanced version (orc_flat_mov_trace_advanced): trace = per FFT frame and channel
+   * { 10 log10 of the mean band NMR, the mean }, trace_fb = per filter-bank block and channel
+   * { RmsModDiff, its weight, noise loudness and missing components of RmsNoiseLoudAsym, AvgLinDist,
+   *   total loudness of ref, test while the loudness gate is closed, pad } */
+  double *trace_fb;
+  unsigned trace_blocks;
 };
 
 static int
@@ -1185,6 +1191,12 @@ fft_frame_advanced (orc_session *s, const float *ref, const float *test)
   mov_nmr (s, &s->acc[MA_SEGNMR], NULL);
   mov_ehs (s, &s->acc[MA_EHS]);
   snr_accumulate (s, ref, test, ORC_FFT_FRAME);
+  if (s->trace && s->frame_counter < s->trace_frames)
+    for (c = 0; c < s->channels; c++) {
+      double *t = s->trace + ((size_t) s->frame_counter * s->channels + c) * 2, mx;
+      nmr_of_channel (s, c, &t[1], &mx);
+      t[0] = 10. * log10 (t[1]);                /* movs.c:1010-1020 */
+    }
   s->frame_counter++;
 }
 
@@ -1206,9 +1218,27 @@ fb_block (orc_session *s, const float *ref, const float *test)
     deinterleave (test, ORC_FB_FRAME, s->channels, c, ch);
     orc_fbmodel_process (&s->fbm, &s->test_fb_st[c], ch);
   }
+  if (s->trace_fb && s->frame_counter_fb < s->trace_blocks && s->loudness_reached == UINT_MAX)
+    for (c = 0; c < s->channels; c++) {         /* the gate's two loudness values of this block, every channel */
+      double *t = s->trace_fb + ((size_t) s->frame_counter_fb * s->channels + c) * 8;
+      t[5] = orc_loudness (b, s->ref_fb_st[c].excitation);
+      t[6] = orc_loudness (b, s->test_fb_st[c].excitation);
+    }
   for (c = 0; c < s->channels; c++)
     preprocess (s, b, c, s->ref_fb_st[c].excitation, s->test_fb_st[c].excitation,
                 s->ref_fb_st[c].unsmeared, s->test_fb_st[c].unsmeared, s->frame_counter_fb);
+  if (s->trace_fb && s->frame_counter_fb < s->trace_blocks)
+    for (c = 0; c < s->channels; c++) {         /* every block, whatever the gates below say */
+      double *t = s->trace_fb + ((size_t) s->frame_counter_fb * s->channels + c) * 8, d2;
+      const double *mr = s->ref_mod[c].modulation, *mt = s->test_mod[c].modulation;
+      const double *ar = s->lev[c].adapted_ref, *at = s->lev[c].adapted_test;
+      moddiff_of_channel (s, b, c, 1., 1, &t[0], &d2, &t[1]);
+      t[2] = noise_loudness (b, 2.5, 0.3, 1., 0.1, mr, mt, ar, at);
+      t[3] = orc_cfg[CFG_SWAP_MOD_PATTS] ? noise_loudness (b, 1.5, 0.15, 1., 0., mt, mr, at, ar)
+                                         : noise_loudness (b, 1.5, 0.15, 1., 0., mr, mt, at, ar);
+      t[4] = noise_loudness (b, 1.5, 0.15, 1., 0., mr, orc_cfg[CFG_SWAP_MOD_PATTS] ? mr : mt, ar,
+                             s->ref_fb_st[c].excitation);
+    }
   if (s->frame_counter_fb >= 125)
     mov_moddiff (s, b, &s->acc[MA_RMSMOD], NULL, NULL);
   if (s->frame_counter_fb >= 125 && s->frame_counter_fb - 13 >= s->loudness_reached) {
@@ -1419,6 +1449,23 @@ orc_flat_mov_trace (int channels, double level_db, const float *ref, size_t n_re
   orc_session *s = orc_session_new (0, channels, level_db);
   s->trace = out;
   s->trace_frames = (unsigned) n_frames;
+  orc_session_push_ref (s, ref, n_ref);
+  orc_session_push_test (s, test, n_test);
+  orc_session_flush (s);
+  orc_session_free (s);
+}
+
+/* The same for the advanced version: out_blocks[block][channel][8], out_frames[frame][channel][2] (struct
+ * orc_session, trace_fb / trace). */
+void
+orc_flat_mov_trace_advanced (int channels, double level_db, const float *ref, size_t n_ref, const float *test,
+                             size_t n_test, int n_blocks, int n_frames, double *out_blocks, double *out_frames)
+{
+  orc_session *s = orc_session_new (1, channels, level_db);
+  s->trace = out_frames;
+  s->trace_frames = (unsigned) n_frames;
+  s->trace_fb = out_blocks;
+  s->trace_blocks = (unsigned) n_blocks;
   orc_session_push_ref (s, ref, n_ref);
   orc_session_push_test (s, test, n_test);
   orc_session_flush (s);

@@ -45,6 +45,8 @@ def lib():
         L.orc_flat_modproc.argtypes = [C.c_int, _dp, C.c_int, _dp, _dp]
         L.orc_flat_tables.argtypes = [C.c_int, _dp]
         L.orc_flat_mov_trace.argtypes = [C.c_int, C.c_double, _fp, C.c_size_t, _fp, C.c_size_t, C.c_int, _dp]
+        L.orc_flat_mov_trace_advanced.argtypes = [C.c_int, C.c_double, _fp, C.c_size_t, _fp, C.c_size_t, C.c_int, C.c_int,
+                                                  _dp, _dp]
         L.orc_di_basic.restype = C.c_double
         L.orc_di_basic.argtypes = [_dp]
         L.orc_di_advanced.restype = C.c_double
@@ -130,6 +132,24 @@ def mov_trace(ref, test, n_frames, level=92.0):
     lib().orc_flat_mov_trace(ch, level, _ptr(ref, _fp), ref.shape[0], _ptr(test, _fp), test.shape[0], n_frames,
                              _ptr(out, _dp))
     return dict(zip(MOV_TRACE, np.moveaxis(out, 2, 0)))
+
+
+MOV_TRACE_ADV_BLOCK = ["rmsmoddiff", "tempwt", "noiseloud", "missing", "lindist", "loudness_ref", "loudness_test"]
+MOV_TRACE_ADV_FRAME = ["segnmr_db", "nmr_mean"]
+
+
+def mov_trace_advanced(ref, test, n_blocks, n_frames, level=92.0):
+    """advanced version, one pair: the MOV layer's values of every filter-bank block and FFT frame before accumulation
+    -> (dict name -> np [blocks, channels] (MOV_TRACE_ADV_BLOCK), dict name -> np [frames, channels] (MOV_TRACE_ADV_FRAME))"""
+    ref = np.ascontiguousarray(ref, dtype=np.float32)
+    test = np.ascontiguousarray(test, dtype=np.float32)
+    ch = ref.shape[1]
+    ob = np.zeros((n_blocks, ch, 8))
+    of = np.zeros((n_frames, ch, 2))
+    lib().orc_flat_mov_trace_advanced(ch, level, _ptr(ref, _fp), ref.shape[0], _ptr(test, _fp), test.shape[0],
+                                      n_blocks, n_frames, _ptr(ob, _dp), _ptr(of, _dp))
+    return (dict(zip(MOV_TRACE_ADV_BLOCK, np.moveaxis(ob[:, :, :7], 2, 0))),
+            dict(zip(MOV_TRACE_ADV_FRAME, np.moveaxis(of, 2, 0))))
 
 
 def fftear(bands, x, n_frames, hop, level=92.0):

@@ -166,3 +166,73 @@ def test_mov_values_match_oracle_per_frame(gpu, case):
             assert np.all(np.abs(got[:, :ch]) < 1e-9) and np.all(np.abs(want[:, :ch]) < 1e-9), name
             continue
         np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-12, err_msg=name)
+
+
+ADV_STAGE_CASES = [
+    dict(kind="synth", seed=5, channels=1, n=72000),
+    dict(kind="synth", seed=6, channels=2, n=60000, test_trim=900),
+    dict(kind="synth", seed=1, channels=2, n=60000),             # leading digital silence
+    dict(kind="synth", seed=9, channels=2, n=40000, atten_shift=9),   # around the detector thresholds
+    dict(kind="synth", seed=26, channels=2, n=40000, identical=1),
+    dict(kind="ats", wave_ref="saw", wave_test="triangle", n=65536, channels=1),
+]
+
+
+@pytest.mark.parametrize("case", ADV_STAGE_CASES,
+                         ids=["mono", "stereo-ragged", "lead-silence", "quiet", "identical", "saw-triangle"])
+def test_advanced_mov_values_match_oracle_per_block_and_frame(gpu, case, fir_mode):
+    """The advanced version's MOV layer block by block and frame by frame, before the accumulators: RmsModDiffA and
+    its weight (movs.c:205-254 with the RMS normalisation of :243-244), the noise loudness and the missing-components
+    term of RmsNoiseLoudAsymA (movs.c:551-577), AvgLinDistA (movs.c:679-706) from the filter-bank back end -- every
+    block, also those the gates of gstpeaq.c:988,996-997 (125 / 13) keep from the accumulators -- the total loudness of
+    the blocks before the loudness gate opens, and SegmentalNMRB of every FFT frame (movs.c:1010-1020) from the
+    55-band back end.  End to end (the goldens) a wrong MOV shows; this says which, where and in which block.
+    HIP filter bank / HIP 55-band front end -> HIP back ends in their debug instantiation, against the oracle's
+    ear models -> pattern layer -> MOV functions on the same samples; both arithmetics of the filter bank."""
+    import torch
+    import gstpeaq_amd
+    import gstpeaq_amd.capi as capi
+    ref, test = case_defs.make_inputs(case)
+    n = min(len(ref), len(test))
+    ref, test = ref[:n], test[:n]
+    ch = ref.shape[1]
+    n_frames = (n - 2048) // 1024 + 2           # all full frames + the zero-padded flush frame
+    n_blocks = -(-n // 192)                     # all full blocks + the zero-padded flush block
+    ctx = gpu.ctx()
+    d_ref, d_test = torch.from_numpy(ref).cuda(), torch.from_numpy(test).cuda()
+    fb = gstpeaq_amd.debug_filterbank(ctx, d_ref, d_test, n_blocks, 320)
+    ff = gstpeaq_amd.debug_frontend(ctx, 55, d_ref, d_test, n_frames)
+    blk, frm, res = capi.debug_backend_advanced(ctx, fb, ff)
+    eblk, efrm = orc.mov_trace_advanced(ref, test, n_blocks, n_frames)
+    loose = gpu.mode() != "default"             # the opt-in engine's filter bank is 1e-4 per block (tests/gpu_common.py)
+    for name in orc.MOV_TRACE_ADV_BLOCK:
+        got, want = blk[name], eblk[name]
+        if name.startswith("loudness"):
+            # evaluated while the gate is closed only (gstpeaq.c:841-845): compare where the oracle evaluated it
+            m = want != 0.
+            np.testing.assert_allclose(got[m], want[m], rtol=1e-4 if loose else 1e-9, err_msg=name)
+            continue
+        # the modulation difference inherits the modulation's cancellation (|L - L_prev| of a stationary signal:
+        # 1e-5 of L), the noise loudness terms the partial loudness's (1 + x)^0.23 - 1 of small x
+        rtol = 1e-6 if name in ("rmsmoddiff", "noiseloud", "missing", "lindist") else 1e-9
+        if loose:
+            rtol = 2e-3
+        if case.get("identical") and name in ("rmsmoddiff", "noiseloud", "missing"):
+            assert np.all(np.abs(got) < 1e-9) and np.all(np.abs(want) < 1e-9), name   # identical signals: exactly nothing
+            continue                                 # (AvgLinDist compares the adapted with the unadapted pattern: not 0)
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-12, err_msg=name)
+    for name in orc.MOV_TRACE_ADV_FRAME:
+        got, want = frm[name], efrm[name]
+        if case.get("identical"):
+            assert np.all(got[:, :ch] < -100) or np.all(np.isinf(got)) or np.allclose(got, want, rtol=1e-6, equal_nan=True), name
+            continue
+        # the noise spectrum's cancellation (Pr - 2 sqrt(Pr Pt) + Pt of nearly equal spectra): 1e-6
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9, err_msg=name)
+    # and the result after the last block and frame is that of the whole pair
+    exp = orc.run_pair(1, ref, test)
+    assert res["frames"] == exp["frames"] == n_frames
+    ok = ~np.isnan(exp["movs"][:5])
+    assert np.array_equal(np.isnan(res["movs"][:5]), ~ok)
+    np.testing.assert_allclose(res["movs"][:5][ok], exp["movs"][:5][ok], rtol=gpu.tol("movs"), atol=1e-9)
+    if not np.isnan(exp["odg"]):
+        assert abs(res["odg"] - exp["odg"]) < 1e-6
