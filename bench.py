@@ -227,6 +227,36 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def fb_source_hash():
+    """the same for the filter-bank kernels (profiles/pmc_frontend.json, key fb_bank_kernel<MfmaF64>)"""
+    import hashlib
+    import re
+    h = hashlib.sha256()
+    for name in ("peaq_device.h", "peaq_fb.hip", "peaq_kernels.h", "peaq_wave.h", "Makefile"):
+        text = (ROOT / "gstpeaq_amd" / "csrc" / name).read_text(errors="replace")
+        if not name == "Makefile":
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", "", text)
+        h.update(name.encode())
+        h.update("".join(text.split()).encode())
+    return h.hexdigest()[:16]
+
+
+def bank_profile_numbers():
+    """Instruction counts of fb_bank_kernel<MfmaF64> per wave and filter-bank block from the committed counter profile
+    (NOT measured in this run; stale if the kernel's sources changed since)."""
+    prof = ROOT / "profiles" / "pmc_frontend.json"
+    try:
+        d = json.loads(prof.read_text()).get("fb_bank_kernel<MfmaF64>")
+        if not d:
+            return None
+        now = fb_source_hash()
+        return dict(d, from_profile=dict(file="profiles/pmc_frontend.json", commit=d.get("commit"), source_hash=d.get("source_hash"),
+                                         source_hash_now=now, stale=d.get("source_hash") != now))
+    except Exception:
+        return None
+
+
 def profile_numbers():
     """Counter-derived figures of the front end and the back end.  They are NOT measured in this run: they come
     from separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh, tools/pmc_mix.sh),
@@ -458,13 +488,32 @@ def main():
             # (it may pass 1: the kernel does less than it is credited with) -- and the kernel's own count stands
             # beside them: the fraction of the matrix pipe's time its matrix instructions fill.
             issued = blocks * args.channels * 2 * 6 * (24 * 8 * 32 + 30 * 4 * 16 * 2) * 2
-            extra = {"reference_flop_per_subsample": 10914 * 6, "matrix_flop_per_subsample": (24 * 8 * 32 + 30 * 4 * 16 * 2) * 2,
+            # what the kernel's SIMDs are busy with: vector and matrix instructions exclude each other on a SIMD,
+            # so issue cycles add -- 4 per FP64 vector instruction and wave, 2 per other vector instruction, 64 per
+            # v_mfma_f64_16x16x4_f64; instruction counts per wave and block from the committed counter profile, the
+            # kernel's time from THIS run's HIP events; 1024 SIMDs at 2.4 GHz
+            bp = bank_profile_numbers()
+            simd_busy = None
+            if bp and fb_s > 0:
+                cyc = bp["valu_fp64_per_wave_block"] * 4 + (bp["valu_per_wave_block"] - bp["valu_fp64_per_wave_block"]) * 2 \
+                    + bp["mfma_per_wave_block"] * 64
+                simd_busy = blocks * args.channels * 2 * 4 * cyc / (1024 * 2.4e9) / fb_s
+            extra = {"simd_busy_frac": simd_busy, "simd_busy_from_profile": bp and bp["from_profile"],
+                     "reference_flop_per_subsample": 10914 * 6, "matrix_flop_per_subsample": (24 * 8 * 32 + 30 * 4 * 16 * 2) * 2,
                      "matrix_flop_per_launch": issued / max(timing["fb_launches"], 1),
                      "matrix_pipe_frac": issued / fb_s / 1e12 / peak if fb_s > 0 else None,
                      "algorithm": "block-sum form: bands 0..23 as running sums over 32-sample blocks (Hann window = three "
                                   "rectangular windows), bands 24..39 direct; fbearmodel.c:399-435"}
+        # `frac`: for the FP64 engine the SIMD-busy fraction (the kernel issues a third of the multiply-adds the reference's
+        # operation count credits it with, so achieved / peak is an algorithm-equivalent rate, not a utilisation -- it
+        # stays in the line as `algorithm_equivalent_frac`); for the other engines achieved / peak as before
+        frac = extra.get("simd_busy_frac") if mode == "f64" and extra.get("simd_busy_frac") else tf / peak
         return {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
-                "frac": tf / peak, "traffic": None, **extra,
+                "frac": frac, "algorithm_equivalent_frac": tf / peak,
+                "frac_is": ("SIMD-busy fraction: (4 x FP64 vector + 2 x other vector + 64 x matrix instructions per wave) x waves "
+                            "/ (1024 SIMDs x 2.4 GHz x kernel time)" if mode == "f64" and extra.get("simd_busy_frac")
+                            else "achieved / peak"),
+                "traffic": None, **extra,
                 "kernel": {"f64": "fb_bank_kernel<MfmaF64>", "f32": "fb_bank_kernel<MfmaF32>", "f16x3": "fb_bank_kernel<MfmaH3>"}[mode],
                 "peak_is": {"f64": "FP64 matrix = vector peak", "f32": "FP32 matrix peak (f32-input MFMA), MI355X_MICROARCH.md",
                             "f16x3": "dense FP16 matrix peak, MI355X_MICROARCH.md; the kernel issues 6x the algorithmic "

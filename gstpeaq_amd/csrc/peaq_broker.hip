@@ -633,14 +633,22 @@ extern "C" int peaq_broker_open(peaq_broker* b, int* session_id) {
     std::vector<int> order(n);
     for (int i = 0; i < n; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return b->shard_open[x] < b->shard_open[y]; });
+    int err_rc = PEAQ_OK;
+    std::string err_msg;
     for (int i : order) {
       int local = -1;
-      if (peaq_broker_open(b->shards[i], &local) == PEAQ_OK) {
+      const int rc = peaq_broker_open(b->shards[i], &local);
+      if (rc == PEAQ_OK) {
         ++b->shard_open[i];
         *session_id = i + n * local;
         return PEAQ_OK;
       }
+      if (rc != PEAQ_ERR_STATE && err_rc == PEAQ_OK) {   // a device's own failure, not "its slots are in use": keep it
+        err_rc = rc;
+        err_msg = "device " + std::to_string(b->shards[i]->ctx->device) + ": " + peaq_err_string();
+      }
     }
+    if (err_rc != PEAQ_OK) return fail(err_rc, "peaq_broker_open: " + err_msg);
     return fail(PEAQ_ERR_STATE, "peaq_broker_open: all session slots are in use");
   }
   std::lock_guard<std::mutex> tick(b->tick_mu);
@@ -765,15 +773,22 @@ extern "C" int peaq_broker_flush(peaq_broker* b, int session_id) {
 extern "C" int peaq_broker_tick(peaq_broker* b, unsigned* n_active) {
   if (!b) return fail(PEAQ_ERR_ARG, "peaq_broker_tick: broker is NULL");
   if (broker_is_multi(b)) {                            // every device's launch of this tick (they run side by side)
+    // EVERY device is ticked, whatever another one reports: a device that failed must not starve the sessions that
+    // live on the others; the first error (with its message) is what the call returns afterwards
     unsigned total = 0;
+    int first_rc = PEAQ_OK;
+    std::string first_msg;
     for (peaq_broker* sh : b->shards) {
       unsigned n = 0;
       const int rc = peaq_broker_tick(sh, &n);
-      if (rc != PEAQ_OK) return rc;
+      if (rc != PEAQ_OK && first_rc == PEAQ_OK) {
+        first_rc = rc;
+        first_msg = peaq_err_string();
+      }
       total += n;
     }
     if (n_active) *n_active = total;
-    return PEAQ_OK;
+    return first_rc == PEAQ_OK ? PEAQ_OK : fail(first_rc, first_msg);
   }
   std::lock_guard<std::mutex> tick(b->tick_mu);
   return broker_tick_checked(b, n_active);

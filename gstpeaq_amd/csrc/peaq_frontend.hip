@@ -325,7 +325,7 @@ struct FrameSrc {
   __device__ __forceinline__ int lane_offset(int lane) const { return channels == 1 ? lane * 8 : lane * 16 + chan * 4; }
   // samples 2 n and 2 n + 1 of this channel, n = lane + 64 r: ONE lane offset for all r (voff = lane_offset),
   // the row as the instruction's scalar offset -- no vector arithmetic per load; the range check covers
-  // vector + scalar + immediate offset (tools/scratch/oob_soffset.hip)
+  // vector + scalar + immediate offset (tools/probes/oob_soffset.hip)
   __device__ __forceinline__ void load2(int r, int voff, float& x0, float& x1) const {
     if (channels == 1) {
       const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, r * 512, 0);

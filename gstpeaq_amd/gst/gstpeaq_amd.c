@@ -112,22 +112,39 @@ shared_broker (gboolean advanced, gint channels)
     return NULL;
   g_mutex_lock (&lock);
   if (!brokers[adv][channels]) {
-    peaq_ctx *ctx = shared_context ();
     const gchar *period = g_getenv ("PEAQ_AMD_BROKER_PERIOD_US");
     const gchar *devs = g_getenv ("PEAQ_AMD_DEVICES");
-    gint devices[64], n_devices = 0, rc;
+    gint devices[64], n_devices = 0, rc = PEAQ_OK;
     if (devs) {
+      /* "0,1,3": device ordinals, nothing else -- a token that is not a non-negative number is an error, not device 0 */
       gchar **tok = g_strsplit (devs, ",", 64);
-      for (gint i = 0; tok[i] && n_devices < 64; i++)
-        if (*tok[i])
-          devices[n_devices++] = atoi (tok[i]);
+      for (gint i = 0; tok[i] && n_devices < 64 && rc == PEAQ_OK; i++) {
+        gchar *t = g_strstrip (tok[i]), *end = NULL;
+        gint64 v;
+        if (!*t)
+          continue;
+        v = g_ascii_strtoll (t, &end, 10);
+        if (end == t || *end || v < 0 || v > 1023) {
+          GST_WARNING ("PEAQ_AMD_DEVICES: '%s' is not a device ordinal; no broker, one session per element", t);
+          rc = PEAQ_ERR_ARG;
+        } else
+          devices[n_devices++] = (gint) v;
+      }
       g_strfreev (tok);
     }
-    if (n_devices > 0)
-      rc = ctx ? peaq_broker_create_multi (devices, n_devices, adv, channels, 92., MAX (atoi (max), n_devices), NULL,
-                                           peaq_ctx_get_fir_mode (ctx), &brokers[adv][channels]) : PEAQ_ERR_DEVICE;
-    else
+    if (rc != PEAQ_OK) {
+      g_mutex_unlock (&lock);
+      return NULL;
+    }
+    if (n_devices > 0) {
+      /* one context per listed device inside the broker; the process-wide context of device 0 is not needed (fir_mode
+       * -1: the engine's default and the environment apply to every device's context alike) */
+      rc = peaq_broker_create_multi (devices, n_devices, adv, channels, 92., MAX (atoi (max), n_devices), NULL, -1,
+                                     &brokers[adv][channels]);
+    } else {
+      peaq_ctx *ctx = shared_context ();
       rc = ctx ? peaq_broker_create (ctx, adv, channels, 92., atoi (max), &brokers[adv][channels]) : PEAQ_ERR_DEVICE;
+    }
     if (rc == PEAQ_OK) {
       if (peaq_broker_start (brokers[adv][channels], period ? (unsigned) atoi (period) : 0) != PEAQ_OK)
         GST_WARNING ("libpeaq_amd: %s", peaq_last_error ());

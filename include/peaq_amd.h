@@ -108,7 +108,12 @@ int peaq_ctx_get_settings (const peaq_ctx *ctx, peaq_settings *s);
  * peaq_ctx_set_fir_fp64(ctx, 0) selects PEAQ_FIR_F16X3, (ctx, 1) PEAQ_FIR_F64; the environment variables
  * PEAQ_AMD_FIR=f64|f16x3|f32 and PEAQ_AMD_FIR_FP64=1|0 set the mode at context creation.  peaq_version() names
  * the default.  Until release 0.2.0 the default was PEAQ_FIR_F16X3.  The basic version and everything
- * downstream of the spreading are FP64 in every mode.  Applies to the launches that follow. */
+ * downstream of the spreading are FP64 in every mode.  Applies to the launches that follow.
+ * Non-finite input samples (NaN / Inf in a float stream): the reference's DC-rejection filters are recursive
+ * (fbearmodel.c:289-303), so one such sample makes every later filter-bank output of that signal NaN there, and it
+ * does here; what differs is only how far BACK it reaches inside the launch that contains it -- PEAQ_FIR_F64
+ * evaluates the long filters through running sums that are re-anchored once per launch (up to 840 blocks), so the
+ * blocks of that launch in front of the sample may read NaN as well.  Finite input is assumed, as by the reference. */
 #define PEAQ_FIR_F32   0
 #define PEAQ_FIR_F64   1
 #define PEAQ_FIR_F16X3 2

@@ -69,5 +69,29 @@ out = {
         "lds_insts_per_wave_frame": bm["SQ_INSTS_LDS"]["sum"] / be_wave_frames,
     },
 }
+# the FP64 filter bank (tools/pmc_fb.sh -> gpurun_out/pmc_fb.json, 1024 pairs x 10 s = 2500 blocks per signal):
+# instructions per wave and filter-bank block, what bench.py's advanced.roofline.simd_busy_frac is computed from
+fbp = G / "pmc_fb.json"
+if fbp.exists():
+    from bench import fb_source_hash  # noqa: E402
+    fb = json.loads(fbp.read_text())
+    bk = next((v for k, v in fb.items() if "fb_bank_kernel<peaq::MfmaF64>" in k), None)
+    if bk:
+        blocks = 2500.0
+        w4 = 1024 * 2 * 2 * 4                          # waves of one pass: signals x 4 (every launch starts them anew)
+        tot = lambda c: bk[c]["sum"] / w4 / blocks if c in bk else 0.0   # noqa: E731
+        f64 = sum(tot(c) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+        out["fb_bank_kernel<MfmaF64>"] = {
+            "commit": commit, "source_hash": fb_source_hash(),
+            "valu_per_wave_block": tot("SQ_INSTS_VALU") - tot("SQ_INSTS_MFMA"),
+            "valu_fp64_per_wave_block": f64,
+            "mfma_per_wave_block": tot("SQ_INSTS_MFMA"),
+            "lds_per_wave_block": tot("SQ_INSTS_LDS"),
+            "lds_atomic_per_wave_block": tot("SQ_INSTS_LDS_ATOMIC"),
+            "lds_idx_active_cycles_per_wave_block": tot("SQ_LDS_IDX_ACTIVE"),
+            "lds_bank_conflict_cycles_per_wave_block": tot("SQ_LDS_BANK_CONFLICT"),
+            "wave_cycles_per_wave_block": tot("SQ_WAVE_CYCLES") * 4,
+            "note": "a tile is 10 blocks; SQ_INSTS_VALU counts the matrix instructions too (taken out above)",
+        }
 (ROOT / "profiles" / "pmc_frontend.json").write_text(json.dumps(out, indent=1) + "\n")
 print(json.dumps(out, indent=1))
