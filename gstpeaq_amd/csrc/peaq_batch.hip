@@ -164,6 +164,8 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
         be_done[b] = e_be;
       }
       c->spans.push_back({e0, e1, 2});
+      c->fb_last_bank_begin = e0;
+      c->fb_last_bank_end = e1;
       prev = nb;
     }
     if (piped)
@@ -282,6 +284,7 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
   HIP_TRY(hipEventRecord(c->batch_begin, stream));
   HIP_TRY(launch_state_init(c->state.as<PairState>(), advanced, n_pairs, stream));
   hipEvent_t fb_done = nullptr;
+  c->fb_last_bank_begin = c->fb_last_bank_end = nullptr;
   if (advanced && max_blocks > 0) {
     // the filter-bank path (its own ear model, accumulators 0, 1, 4) is independent of the FFT
     // path (accumulators 2, 3): it runs on a third stream from here on and joins at the end
@@ -336,8 +339,21 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
   // per-frame records are double buffered.
   hipEvent_t back_done[2] = {nullptr, nullptr};
   unsigned chunk = 0;
+  // Advanced version: the last chunks of the FFT path are held back until the filter-bank path's last bank launch
+  // is through.  An advanced pass ends with that launch's back end alone on the device (one workgroup per pair walking
+  // 840 blocks: 12 ms at a fraction of the machine) while all FFT chunks, ready from the start, have long run beside
+  // the FIRST bank launch and slowed it by their own time; two chunks of frontend_kernel<55> are about what the tail
+  // has room for (profiles/r05_timeline_adv.txt).  PEAQ_AMD_ADV_DEFER=<chunks>[b] (development): other counts; "b" =
+  // wait for the last bank launch's begin instead of its end.
+  const unsigned n_chunks = (max_frames + fc - 1) / fc;
+  static const int defer_env = [] { const char* e = std::getenv("PEAQ_AMD_ADV_DEFER"); return e && *e ? std::atoi(e) : -1; }();
+  static const bool defer_begin = [] { const char* e = std::getenv("PEAQ_AMD_ADV_DEFER"); return e && std::strchr(e, 'b'); }();
+  const unsigned defer = (!advanced || !c->fb_last_bank_end || PEAQ_DEV_SERIAL_KERNELS) ? 0u
+                         : std::min<unsigned>(defer_env >= 0 ? (unsigned)defer_env : 2u, n_chunks > 4 ? n_chunks - 4 : 0u);
   for (uint32_t f0 = 0; f0 < max_frames; f0 += fc, ++chunk) {
     const unsigned nf = std::min<uint32_t>(fc, max_frames - f0);
+    if (defer && chunk == n_chunks - defer)
+      HIP_TRY(hipStreamWaitEvent(stream, defer_begin ? c->fb_last_bank_begin : c->fb_last_bank_end, 0));
     double* recs = (chunk & 1) ? c->records2.as<double>() : c->records.as<double>();
     fa.frame0 = f0;
     fa.frames_per_launch = nf;

@@ -135,6 +135,7 @@ struct peaq_ctx {
   hipStream_t aux2 = nullptr;  // advanced: the filter-bank path runs here, beside the FFT path
   hipStream_t aux3 = nullptr, aux4 = nullptr;   // ... its high-pass stage and its back end (3-stage pipeline)
   hipEvent_t batch_begin = nullptr, batch_end = nullptr;
+  hipEvent_t fb_last_bank_begin = nullptr, fb_last_bank_end = nullptr;   // of the running batch's filter-bank path (pool events)
   bool batch_pending = false;
   std::vector<TimedSpan> spans;
   std::vector<hipEvent_t> event_pool;
