@@ -345,7 +345,7 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
   // the FIRST bank launch and slowed it by their own time; two chunks of frontend_kernel<55> are about what the tail
   // has room for (profiles/r05_timeline_adv.txt).  PEAQ_AMD_ADV_DEFER=<chunks>[b] (development): other counts; "b" =
   // wait for the last bank launch's begin instead of its end.
-  const unsigned n_chunks = (max_frames + fc - 1) / fc;
+  const unsigned n_chunks = fc ? (max_frames + fc - 1) / fc : 0u;   // (a pair of two empty signals has no frames at all)
   static const int defer_env = [] { const char* e = std::getenv("PEAQ_AMD_ADV_DEFER"); return e && *e ? std::atoi(e) : -1; }();
   static const bool defer_begin = [] { const char* e = std::getenv("PEAQ_AMD_ADV_DEFER"); return e && std::strchr(e, 'b'); }();
   const unsigned defer = (!advanced || !c->fb_last_bank_end || PEAQ_DEV_SERIAL_KERNELS) ? 0u
