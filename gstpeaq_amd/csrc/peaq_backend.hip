@@ -331,12 +331,16 @@ __device__ __forceinline__ double total_loudness(const BandLane<NB, SLOTS>& bl, 
   return wave_sum(t) * (24. / NB);
 }
 
-// movs.c:709-743
-template <int NB, int SLOTS, class TAB>
+// movs.c:709-743.  `lead`: the factor (ethres / stest)^0.23 per slot -- computed here (KEEP: and handed back) or taken
+// from a call with the same thres_fac, s0 and mod_test (USE): RmsNoiseLoudAsym's missing-components term and AvgLinDist
+// (movs.c:551-577, 679-706) share it, a logarithm and an exponential per band and block.
+enum LeadMode { LEAD_OWN, LEAD_KEEP, LEAD_USE };
+template <int NB, int SLOTS, class TAB, LeadMode LM = LEAD_OWN>
 __device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, const TAB& bt,
                                                  double alpha, double thres_fac, double s0, double nl_min,
                                                  const double (&mod_ref)[SLOTS], const double (&mod_test)[SLOTS],
-                                                 const double (&e_ref)[SLOTS], const double (&e_test)[SLOTS]) {
+                                                 const double (&e_ref)[SLOTS], const double (&e_test)[SLOTS],
+                                                 double* lead = nullptr) {
   double nl = 0.;
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
@@ -346,7 +350,13 @@ __device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, 
       const double ethres = bt.internal_noise(bl.band(s));
       const double beta = be_exp(div_fast(-alpha * (e_test[s] - e_ref[s]), e_ref[s]));
       // (ethres / stest)^0.23 from the logarithms: ln ethres is a table entry
-      nl += be_exp(0.23 * (bt.ln_internal_noise(bl.band(s)) - bt.log(stest))) *
+      double ld;
+      if (LM == LEAD_USE)
+        ld = lead[s];
+      else
+        ld = be_exp(0.23 * (bt.ln_internal_noise(bl.band(s)) - bt.log(stest)));
+      if (LM == LEAD_KEEP) lead[s] = ld;
+      nl += ld *
             (bt.pow(1. + div_fast(fmax(stest * e_test[s] - sref * e_ref[s], 0.), ethres + sref * e_ref[s] * beta), 0.23) -
              1.);
     }
@@ -886,10 +896,12 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
       // patterns of the missing-components term ...
       const bool swap = a.cfg.swap_mod_patts != 0;   // workgroup-uniform
       const double nl = noise_loudness<NB, SLOTS>(bl, bt, 2.5, 0.3, 1., 0.1, mr, mt, ad_ref, ad_test);
-      const double mc = noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 1., 0., swap ? mt : mr, swap ? mr : mt, ad_test,
-                                                  ad_ref);
+      double lead[SLOTS] = {};                       // (ethres / stest)^0.23: the same stest in both calls below
+      const double mc = noise_loudness<NB, SLOTS, GlobalTabs, LEAD_KEEP>(bl, bt, 1.5, 0.15, 1., 0., swap ? mt : mr,
+                                                                         swap ? mr : mt, ad_test, ad_ref, lead);
       // ... and (movs.c:679-706) takes the reference modulation twice; unadapted FB excitation
-      const double ld = noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 1., 0., mr, swap ? mr : mt, ad_ref, er);
+      const double ld = noise_loudness<NB, SLOTS, GlobalTabs, LEAD_USE>(bl, bt, 1.5, 0.15, 1., 0., mr, swap ? mr : mt, ad_ref,
+                                                                        er, lead);
       const bool open = blk >= 125 && blk - 13 >= loud_reached;
       if (open && lane == MA_NLASYM) {
         v0 = nl;
