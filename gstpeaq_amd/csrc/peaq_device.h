@@ -182,6 +182,8 @@ struct FbTables {               // fbearmodel.c:57-61,182-225
   double bs_seg[kBsPairs][6][64][2];
   double mfd_re[kMfdSteps * 64];        // the direct tile's A operands, lane = band - 24 + 16 (d - kMfdD0 - 4 s)
   double mfd_im[kMfdSteps * 64];
+  double log_tab[130][2];               // CommonTables::log_tab again: the bank kernel's slope exponents take their logarithms
+                                        // from a copy in LDS (peaq_fb.hip), and its arguments carry no CommonTables
 };
 
 // ---- per-frame record: front end -> back end --------------------------------

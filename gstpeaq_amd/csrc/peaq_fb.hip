@@ -555,6 +555,8 @@ __device__ __forceinline__ void fir_mfma_tail(BankLds<typename M::T>& sh, const 
 // ---------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) double kdouble;   // read through the scalar cache when the address is uniform
 typedef const __attribute__((address_space(4))) int kint;
+constexpr int kLogTabAt = 512;                       // FP64 engine: the logarithm table's place in e1 / ex (doubles from e1[0][0]), behind the
+                                                     // left-edge coefficients / the slopes of bands 32 .. 39 (512 doubles each in their phase)
 constexpr int kStRow = 72;                           // staging row stride in doubles: eight front slots + 64 outputs (= 8 mod 32: the rows of
                                                      // the four chains of a half wave start on four different bank groups)
 constexpr int kStOrg = 8;                            // index of output 0 in a row (entries in front: outputs < 0 of the shifted rows)
@@ -1302,6 +1304,16 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     double2* az = reinterpret_cast<double2*>(&sh.a.re[0][0]);
     for (int i = tid; i < 2 * kFbBands * kACols / 2; i += 256) az[i] = make_double2(0., 0.);
   }
+  double ltab_in[2] = {0., 0.};                      // FP64 engine: this thread's entries of the logarithm table, on their way to LDS
+  auto request_ltab = [&]() {
+    if constexpr (sizeof(WT) == 8) {
+      const double* lt = &fb->log_tab[0][0];
+      asm volatile("" : "+v"(lt));                   // (not hoisted out of the tile loop: four more registers over all phases)
+      ltab_in[0] = lt[tid_k];
+      ltab_in[1] = lt[256 + (tid_k & 3)];
+    }
+  };
+  request_ltab();
   for (unsigned b0 = 0; b0 < nb_mine; b0 += kTileBlocks) {
     // The thread's indices are re-derived (as far as the compiler can tell) in every tile: otherwise it computes the
     // LDS addresses of ALL phases once in front of the loop -- some two hundred registers, most of which the FP64
@@ -1340,7 +1352,16 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
       double2* az = reinterpret_cast<double2*>(&sh.a.re[0][0]);
       for (int i = tid; i < kFbBands * kACols; i += 256) az[i] = make_double2(0., 0.);
     }
+    // FP64 engine: the logarithm table of the slope exponents (log_tab, peaq_wave.h; 260 doubles) into the part of
+    // e1 / ex that neither the left-edge coefficients of phase 1 nor the slope exchange of phase 2 use -- every tile,
+    // because phase 5 writes its excitations there; requested in front of the barrier, stored behind it (the last
+    // tile's record writers may still be reading ex in front of it)
     __syncthreads();
+    if constexpr (sizeof(WT) == 8) {
+      double* ltab_w = &sh.e1[0][0] + kLogTabAt;
+      ltab_w[tid] = ltab_in[0];
+      if (tid < 4) ltab_w[256 + tid] = ltab_in[1];
+    }
     FB_MARK(0);
     // ---- phase 1: the complex FIR filters (fbearmodel.c:399-435) as a GEMM on the matrix cores ---
     if constexpr (sizeof(WT) == 8) {
@@ -1455,7 +1476,14 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         if (i % 5 == 0) {
 #pragma unroll
           for (int k = 0; k < 5; ++k) dist_s5[k] = re[i + k] * re[i + k] + im[i + k] * im[i + k];
-          log_nonneg_n<5>(dist_s5);
+          if constexpr (sizeof(WT) == 8) {
+            // logarithms from the table in LDS (17 instead of 31 instructions each; five independent evaluations)
+            const double* ltab = &sh.e1[0][0] + kLogTabAt;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) dist_s5[k] = log_tab_nonneg(dist_s5[k], ltab);
+          } else {
+            log_nonneg_n<5>(dist_s5);
+          }
 #pragma unroll
           for (int k = 0; k < 5; ++k) dist_s5[k] = fmin(4. * kLnDist, sh.c0[wave_band(wv, i + k)] + kC1 * dist_s5[k]);
           exp_fast_n<5>(dist_s5);
@@ -1508,7 +1536,8 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
       // e1 / ex (idle until phase 4)
       double* wcol = reinterpret_cast<double*>(sh.win.v);
       double* xtra = &sh.e1[0][0];
-      static_assert(sizeof(sh.e1) + sizeof(sh.ex) >= 8 * 64 * sizeof(double) && kTileSub <= 60, "room for the slopes of bands 32 .. 39");
+      static_assert(sizeof(sh.e1) + sizeof(sh.ex) >= (kLogTabAt + 2 * kLogTabEntries + 2) * sizeof(double) && kLogTabAt >= 8 * 64 &&
+                        kTileSub <= 60, "room for the slopes of bands 32 .. 39 and the logarithm table behind them");
 #pragma unroll
       for (int i = 0; i < 10; ++i) {
         const int b = wave_band(wv, i);                                // (wave-uniform)
@@ -1640,6 +1669,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     }
     __syncthreads();
     FB_MARK(11);
+    if (b0 + kTileBlocks < nb_mine) request_ltab();  // the next tile's copy of the logarithm table (see phase 0)
     for (int item = tid; item < kFbBands * (int)nvb; item += 256) {
       const int bl = item / kFbBands, b = item - bl * kFbBands;      // 40 consecutive doubles per block
       double* rec = a.records + ((size_t)(pair * a.blocks_per_launch + b0 + bl) * a.channels + chan) * kFbRecDoubles;

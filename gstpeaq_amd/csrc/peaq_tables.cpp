@@ -102,6 +102,8 @@ static void spread_reference_order(const BandTables& t, const std::vector<double
   for (int i = 0; i < nb; ++i) e2[i] = std::pow(e2[i], 2.5);
 }
 
+void fill_log_tab(double (*tab)[2]);
+
 void build_fft_band_tables(int bands, BandTables& t) {
   std::memset(&t, 0, sizeof t);
   const int n = kFrame;
@@ -372,6 +374,7 @@ void build_fb_band_tables(BandTables& t, FbTables& fb) {
     const double c = std::cos(kPi * (k - 5.0) / 12.0);
     fb.back_mask[k] = c * c * 0.9761 / 6.0;     // what this host's libm gives; the kernel's compile-time copies
   }                                              // (kBackMask, peaq_device.h) are compared in fb_tables_selfcheck()
+  fill_log_tab(fb.log_tab);
   fill_common_bands(t, fc, kFbFrame, 1.26539, 0.004, 0.020);  // fbearmodel.c:171-177
   t.delta_z = 0.0;
 }
@@ -417,16 +420,20 @@ void build_common_tables(CommonTables& c) {
     c.ehs_window[i] = 0.81649658092773 * (1.0 - std::cos(2 * kPi * i / 255.0)) / 256.0;
     c.ehs_window_centred[i] = 0.81649658092773 * (1.0 + std::cos(2 * kPi * i / 511.0)) / 256.0;
   }
-  for (int i = 0; i < 130; ++i) {                     // log_tab (peaq_device.h)
+  fill_log_tab(c.log_tab);
+}
+
+void fill_log_tab(double (*tab)[2]) {                 // log_tab (peaq_device.h), 130 entries
+  for (int i = 0; i < 130; ++i) {
     const long double centre = 1.0L + i / 128.0L, ln2 = 0.693147180559945309417232121458176568L;
-    c.log_tab[i][0] = (double)(2.0L / centre);
+    tab[i][0] = (double)(2.0L / centre);
     // the centre that the ROUNDED reciprocal stands for: r = fma(m, [i][0], -1) is then exact with respect to it,
     // and the only rounding left in ln m = log1p(r) + ln C - ln 2 is that of the entry itself
-    const long double c_eff = 2.0L / (long double)c.log_tab[i][0];
+    const long double c_eff = 2.0L / (long double)tab[i][0];
     // the lower bins count one binade less in e instead of carrying - ln 2
-    c.log_tab[i][1] = (double)(i < kLogTabFold ? std::log(c_eff) : std::log(c_eff) - ln2);
+    tab[i][1] = (double)(i < kLogTabFold ? std::log(c_eff) : std::log(c_eff) - ln2);
   }
-  c.log_tab[128][1] = 0.;                             // ln 2 - ln 2 (the long-double difference is 0 anyway)
+  tab[128][1] = 0.;                                   // ln 2 - ln 2 (the long-double difference is 0 anyway)
 }
 
 // Self-check of the FP64 engine's filter-bank tables on the host (no device involved; tests/test_capi_host.py):
