@@ -592,9 +592,60 @@ void frontend_kernel(FrontendArgs a) {
   }
 
   FE_MARK(2);                                        // the test wave's zero threshold
+  const double* pw_ref = lds + kOffPw;
+  double* pw_test = lds + kUnitDoubles + kOffPw;
+  double* sa = lds + kOffScratch;                            // [512] the reference unit's scratch
+  double* sb = lds + kUnitDoubles + kOffScratch;             // [512] the test unit's scratch
+  if constexpr (kAdvanced) {
+    // Advanced version: of the test signal only the weighted spectrum is used -- noise in bands and EHS,
+    // process_fft_block_advanced gstpeaq.c:924-959 -- so its wave has no band phase of its own.  It used to wait at the
+    // barrier behind the reference wave's (a quarter of its lifetime, tools/fe_profile.py) and do its share afterwards;
+    // now the waves meet HERE, with both weighted spectra in LDS, and the test wave does everything that needs both
+    // while the reference wave groups and spreads: all log ratios of the error-harmonic structure (into ITS scratch
+    // area: the reference wave's holds the band sums), then the noise spectrum in place and its band sums.  The
+    // reference wave reads none of what it writes before the second barrier.
+    __syncthreads();
+    if (sig == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {                  // movs.c:1383-1391: d[k] = ln(Pw_test / Pw_ref), k < 512
+        const int k = lane + 64 * j;
+        const double fr = pw_ref[k], ft = pw_test[k];
+        sb[k] = (fr == 0. && ft == 0.) ? 0. : FE_LOG_NONNEG(ft / fr, ltab);   // +-inf when one side is digital silence
+      }
+      FE_MARK(8);                                    // log ratios
+      wave_lds_fence();
+      {
+        constexpr int kSteps = (kPwLen + 63) / 64;   // movs.c:992-996, as in the basic version below
+        double r[kSteps], t[kSteps];
+#pragma unroll
+        for (int i = 0; i < kSteps; ++i) {
+          const int k = lane + 64 * i < kPwLen ? lane + 64 * i : 0;
+          r[i] = pw_ref[k];
+          t[i] = pw_test[k];
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < kSteps; ++i)
+          if (lane + 64 * i < kPwLen) pw_test[lane + 64 * i] = r[i] - 2 * sqrt_pos(r[i] * t[i]) + t[i];
+        if (lane == 0) xch[0] = 0.;                  // the band sums' zero slot (no bandwidth exchange in this version)
+      }
+      wave_lds_fence();
+      const int zero_at = (int)(xch - pw_test);
+      if (lane < (NB + 1) / 2) {
+        const int b1 = lane, b2 = NB - 1 - lane;
+        rec[kRecNoise + b1] = group_band(edge1, pw_test, zero_at);
+        if (b2 != b1) rec[kRecNoise + b2] = group_band(edge2, pw_test, zero_at);
+      } else if (lane < (NB + 1) / 2 + kBandStride - NB) {
+        rec[kRecNoise + NB + lane - (NB + 1) / 2] = 0.;  // padding slots of the band vector
+      }
+      if (lane == 0) {
+        rec[kRecBwRef] = 0.;
+        rec[kRecBwTest] = 0.;
+      }
+      FE_MARK(10);                                   // test wave: noise spectrum + grouping
+    }
+  }
   // ---- critical bands, internal noise, spreading ------------------------------------
-  // (advanced version: of the test signal only the weighted spectrum is used -- noise in bands and EHS,
-  // process_fft_block_advanced gstpeaq.c:924-959 -- so its wave goes straight to the barrier)
   if (!kAdvanced || sig == 0) {
     // lane owns bands 2 lane and 2 lane + 1
     const double* pw = unit + kOffPw;
@@ -703,14 +754,14 @@ void frontend_kernel(FrontendArgs a) {
     bw_ref = top_bin(10. * xch[0], 921, false);
     if (lane == 0) xch[1] = (double)bw_ref;          // read by the test wave behind the next barrier
   }
-  const double* pw_ref = lds + kOffPw;
-  double* pw_test = lds + kUnitDoubles + kOffPw;
-  double* sa = lds + kOffScratch;                            // [512] the reference unit's scratch
-  double* sb = lds + kUnitDoubles + kOffScratch;             // [512] the test unit's scratch
+  if (kAdvanced && sig == 1) {                       // advanced version: the test wave is through (the log ratios are in sb)
+    if (pf_keep == 123456.789f) rec[kRecScalars + 15] = 1.;   // (keeps its prefetch alive, see the kernel's last line)
+    return;
+  }
 
   // ---- error harmonic structure, part 1 (movs.c:1383-1391): d[k] = ln(Pw_test / Pw_ref), k < 512.
   // The test wave takes 6 of the 8 values per lane: its tail (noise spectrum) is the shorter one.
-  {
+  if constexpr (!kAdvanced) {
     double* dlog = sa;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -720,9 +771,11 @@ void frontend_kernel(FrontendArgs a) {
       dlog[k] = (fr == 0. && ft == 0.) ? 0. : FE_LOG_NONNEG(ft / fr, ltab);   // +-inf when one side is digital silence
     }
   }
-  FE_MARK(8);                                        // log ratios
-  __syncthreads();
-  FE_MARK(9);                                        // barrier
+  if constexpr (!kAdvanced) {
+    FE_MARK(8);                                      // log ratios
+    __syncthreads();
+    FE_MARK(9);                                      // barrier
+  }
   if (!kAdvanced && sig == 1) {
     bw_ref = (int)xch[1];
     if (bw_ref > 346) bw_test = top_bin(3.16227766016838 * thr, bw_ref, true);
@@ -770,7 +823,7 @@ void frontend_kernel(FrontendArgs a) {
     cplx u[8];
     double g[4], run_in;                             // window-energy increments of this lane's four lags
     {
-      const double* d = sa;
+      const double* d = kAdvanced ? sb : sa;           // (advanced version: written by the test wave, see above)
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const double v = d[lane + 64 * r];

@@ -18,13 +18,14 @@ PHASES = ["reductions+flags (after the loads)", "FFT+split", "zero threshold of 
           "ref: FFT-512 | test: noise+grouping", "ref: product+inverse", "ref: normalise+FFT-256+peak",
           "work-item decoding (after start-up)", "sample loads + window", "wave start-up + kernel arguments"]
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+ADV = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 ctx = gstpeaq_amd.Context(0)
 ref, test = gstpeaq_amd.synth_fill(ctx, 1, pairs, 2, 480000)
-gstpeaq_amd.batch_run(ctx, 0, ref, test)
+gstpeaq_amd.batch_run(ctx, ADV, ref, test)
 buf = (C.c_ulonglong * 64)()
 ctx.L.peaq_debug_frontend_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert ctx.L.peaq_debug_frontend_profile(ctx.h, buf) == 0
-gstpeaq_amd.batch_run(ctx, 0, ref, test)
+gstpeaq_amd.batch_run(ctx, ADV, ref, test)
 assert ctx.L.peaq_debug_frontend_profile(ctx.h, buf) == 0
 out = {}
 for sig, name in ((0, "ref"), (1, "test")):
