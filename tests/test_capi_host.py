@@ -51,6 +51,16 @@ def test_no_silent_cpu_fallback(lib):
         gstpeaq_amd.Context(0)
 
 
+def test_measurement_entry_points_check_their_arguments(lib):
+    """peaq_calibrate / peaq_batch_last_clock / peaq_debug_backend_advanced: NULL handles are refused with a message"""
+    for fn, args in ((lib.peaq_calibrate, (None, 0, None)), (lib.peaq_batch_last_clock, (None, None)),
+                     (lib.peaq_debug_backend_advanced, (None, 1, 1, None, 1, None, None, None, None))):
+        fn.restype = C.c_int
+        assert fn(*args) == -1                                           # PEAQ_ERR_ARG
+        lib.peaq_last_error.restype = C.c_char_p
+        assert b"NULL" in lib.peaq_last_error()
+
+
 def test_argument_checks(lib):
     assert lib.peaq_ctx_create(0, None) == -1      # PEAQ_ERR_ARG
     assert lib.peaq_session_push(None, 0, None, 0) == -1
