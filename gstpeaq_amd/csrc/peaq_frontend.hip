@@ -675,8 +675,8 @@ void frontend_kernel(FrontendArgs a) {
     FE_MARK(3);                                        // band grouping
     // Upward spreading, Kabal (27): E2[j] += Ene[i] a_i^(j-i) for j > i, a_i = aUCEe[i] -- the reference's O(B^2) loop
     // (fftearmodel.c:657-667).  Every band's contributions are a geometric sequence along the target bands; they used
-    // to be scattered into LDS with one atomic per step (an LDS atomic costs this kernel five FP64 instructions'
-    // worth of time, profiles/r05_ab_basic.txt).  Now the ACCUMULATORS travel instead: the pair of sums for the bands
+    // to be scattered into LDS with one atomic per step -- 40 % of the time of an LDS array that was 54 % busy, and an
+    // LDS store costs this kernel more than two FP64 instructions (profiles/r05_ab_basic.txt).  Now the ACCUMULATORS travel instead: the pair of sums for the bands
     // of lane M sits in lane M - k while the sources add what they send k lanes up, and moves one lane up (two DPP
     // moves per double, zeros entering at lane 0) after every step, k = kLanes .. 1 -- so it arrives home complete,
     // and sums for bands that do not exist leave at the top.  Walking k DOWN means walking each source's sequence
