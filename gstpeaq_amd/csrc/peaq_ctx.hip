@@ -283,23 +283,24 @@ extern "C" int peaq_calibrate(peaq_ctx* c, int iterations, peaq_calibration* out
   TmpBuf sink, ticks;
   HIP_TRY(sink.reserve((size_t)waves * 64 * sizeof(double)));
   HIP_TRY(ticks.reserve((size_t)waves * 2 * sizeof(unsigned long long)));
-  hipEvent_t e0 = c->batch_begin, e1 = c->batch_end;
-  if (c->batch_pending) {                            // the events belong to an unread batch timing: settle it first
-    HIP_TRY(hipEventSynchronize(c->batch_end));
-  }
+  if (c->batch_pending) HIP_TRY(hipEventSynchronize(c->batch_end));   // a batch still running would share the device with the probe
   hipLaunchKernelGGL(calib_kernel, dim3(waves), dim3(64), 0, 0, sink.as<double>(), ticks.as<unsigned long long>(), 200);   // warm
-  hipEvent_t t0, t1;
-  HIP_TRY(hipEventCreate(&t0));
-  HIP_TRY(hipEventCreate(&t1));
-  (void)e0; (void)e1;
-  HIP_TRY(hipEventRecord(t0, 0));
+  struct Events {                                    // destroyed on every way out
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } ev;
+  HIP_TRY(hipEventCreate(&ev.a));
+  HIP_TRY(hipEventCreate(&ev.b));
+  HIP_TRY(hipEventRecord(ev.a, 0));
   hipLaunchKernelGGL(calib_kernel, dim3(waves), dim3(64), 0, 0, sink.as<double>(), ticks.as<unsigned long long>(), iterations);
-  HIP_TRY(hipEventRecord(t1, 0));
-  HIP_TRY(hipEventSynchronize(t1));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ev.b, 0));
+  HIP_TRY(hipEventSynchronize(ev.b));
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
-  (void)hipEventDestroy(t0);
-  (void)hipEventDestroy(t1);
+  HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
   std::vector<unsigned long long> h((size_t)waves * 2);
   HIP_TRY(hipMemcpy(h.data(), ticks.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   double shader = 0., wall = 0.;
