@@ -42,8 +42,9 @@ struct HpWalk {
   // Identical operation order to the reference, no FMA contraction.
   __device__ __forceinline__ double step(double in) {
 #pragma clang fp contract(off)
-    const double ya = in - 2. * x1 + x2 + 1.99517 * y1a - 0.995174 * y2a;
-    const double yb = ya - 2. * y1a + y2a + 1.99799 * y1b - 0.997998 * y2b;
+    // (in - 2 x1: doubling is exact, so the fused form rounds once to the same value as the two operations)
+    const double ya = __builtin_fma(-2., x1, in) + x2 + 1.99517 * y1a - 0.995174 * y2a;
+    const double yb = __builtin_fma(-2., y1a, ya) + y2a + 1.99799 * y1b - 0.997998 * y2b;
     x2 = x1;
     x1 = in;
     y2a = y1a;
@@ -63,11 +64,13 @@ struct HpWalk {
 #define PEAQ_HP_WAVES 4
 #endif
 constexpr int kHpWaves = PEAQ_HP_WAVES;
-__global__ __launch_bounds__(64 * kHpWaves) void fb_hp_kernel(FbFrontArgs a, unsigned n_signals) {
-  __shared__ double tiles[kHpWaves][64][9];         // per wave: [signal in wave][8 samples], padded
+// (at most 256 registers: a wave of this kernel shares its SIMD with one of the bank kernel's, 240 of the 512)
+__global__ __launch_bounds__(64 * kHpWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void fb_hp_kernel(FbFrontArgs a,
+                                                                                                       unsigned n_signals) {
+  __shared__ double tiles[kHpWaves][64][17];        // per wave: [signal in wave][16 samples], padded
   __shared__ float inbufs[kHpWaves][64 * 18];
   const int lane = threadIdx.x & 63;
-  double (*tile)[9] = tiles[threadIdx.x >> 6];
+  double (*tile)[17] = tiles[threadIdx.x >> 6];
   float* inbuf = inbufs[threadIdx.x >> 6];
   const unsigned g0 = blockIdx.x * (64 * kHpWaves) + (threadIdx.x & ~63u);
   const unsigned g = g0 + lane;
@@ -173,10 +176,111 @@ __global__ __launch_bounds__(64 * kHpWaves) void fb_hp_kernel(FbFrontArgs a, uns
   f4u nxt[4];
   load_chunk(0, nxt);
   const int in_at = (2 * (lane / (2 * C)) + sig) * kInStride + chan;       // this lane's first sample of a chunk in LDS
+
+  // Where the transposed tiles go: store instruction r carries the signals 8 r + lane / 8 (their rows and block
+  // counts fetched once -- as shuffles in the loop they were two LDS round trips in front of every store)
+  double* out_row[8];
+  unsigned nb_s[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int src = r * 8 + (lane >> 3);
+    out_row[r] = rows + (size_t)(unsigned)__shfl((int)state_idx, src, 64) * row_len + kFbRing;
+    nb_s[r] = (unsigned)__shfl((int)nb_mine, src, 64);
+  }
+
+  // FAST blocks: all 64 lanes live, the block inside every lane's signal and block count, and the sixteen-byte
+  // pieces of its chunks and of the chunk after it inside their rows.  Such a block is straight-line code -- no
+  // bounds checks, no zero padding, unconditional loads and stores -- and that is what makes it fast: a wave's vector
+  // memory operations return through ONE in-order counter, and with loads or stores under lane masks the compiler
+  // has to wait for the counter to reach zero wherever it needs a load's data, i.e. for the acknowledgement of every
+  // store of the chunk before (measured: the walk took 410 cycles per sample, 145 of them instructions).
+  unsigned f_lo, f_hi;
+  {
+    const long long kBig = 1ll << 40;
+    auto ceil_div = [](long long x, long long d) { return x <= 0 ? 0ll : (x + d - 1) / d; };
+    auto floor_div = [](long long x, long long d) { return x <= 0 ? 0ll : x / d; };
+    // chunks [c_lo, c_hi) of the launch lie inside this lane's signal; chunks [l_lo, l_hi) inside its loader row
+    const long long c_lo = ceil_div(-my_s0, 16), c_hi = min((long long)nb_mine * (kFbFrame / 16), floor_div((long long)n_sig - my_s0, 16));
+    const long long l_lo = ceil_div(-ld_s0, 16), l_hi = floor_div((long long)a.pair_stride - ld_s0, 16);
+    // block bl: chunks 12 bl .. 12 bl + 11 computed, 12 bl + 1 .. 12 bl + 12 loaded
+    long long lo = max(ceil_div(c_lo, 12), ceil_div(l_lo - 1, 12));
+    long long hi = min(floor_div(c_hi, 12), l_hi >= 13 ? (l_hi - 13) / 12 + 1 : 0ll);
+    if (!live || !ld_live) hi = 0;
+    unsigned ulo = (unsigned)min(lo, kBig >> 12), uhi = (unsigned)min(hi, kBig >> 12);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      ulo = max(ulo, (unsigned)__shfl_xor((int)ulo, d, 64));
+      uhi = min(uhi, (unsigned)__shfl_xor((int)uhi, d, 64));
+    }
+    f_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)ulo);
+    f_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)uhi);
+  }
+  const float* __restrict__ ld_ptr = ld_base + ld_s0 * C + 4 * ld_piece0;   // (never dereferenced outside the row)
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+
   for (unsigned bl = 0; bl < nb_max; ++bl) {
     const bool mine = bl < nb_mine;
-    float sum = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;   // |x| of the last five samples
     int above = 0;
+    if (bl >= f_lo && bl < f_hi) {
+      // ---- fast block ----
+      // The detector of gstpeaq.c:1083-1096 in the same arithmetic with less of it: |x| as a double is the absolute
+      // value of the sample's double, the history is kept converted, and the threshold 200 / 32768 is a float, so
+      // "sum >= threshold at some i >= 5" is a float maximum compared once per block.
+      double sumd = 0., g0d = 0., g1d = 0., g2d = 0., g3d = 0., g4d = 0.;
+      float smax = 0.f;
+      auto fast_chunk = [&](const int kc, const bool block_head) __attribute__((always_inline)) {
+        const unsigned c = bl * (kFbFrame / 16) + kc;
+        float xc[16];
+        {
+          float* dst = inbuf + ld_row * kInStride + 4 * ld_piece0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            reinterpret_cast<float2*>(dst + 4 * j)[0] = make_float2(nxt[j][0], nxt[j][1]);
+            reinterpret_cast<float2*>(dst + 4 * j)[1] = make_float2(nxt[j][2], nxt[j][3]);
+          }
+          wave_lds_fence();
+#pragma unroll
+          for (int k = 0; k < 16; ++k) xc[k] = inbuf[in_at + k * C];
+          wave_lds_fence();
+          const float* __restrict__ src = ld_ptr + (size_t)(16u * (c + 1)) * C;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) nxt[j] = *reinterpret_cast<const f4u*>(src + 4 * j);
+        }
+        double y[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const double xd = (double)xc[k];
+          y[k] = w.step(xd * a.level_factor);
+          peak = fmax(peak, fabs(y[k]));
+          const double ax = fabs(xd);
+          sumd = (double)(float)(sumd + (ax - g0d));                     // (the history starts as zeros: i < 5 adds |x| itself)
+          smax = fmaxf(smax, (float)sumd);
+          if (block_head && k == 4) smax = 0.f;                          // tested from i = 5 on
+          g0d = g1d; g1d = g2d; g2d = g3d; g3d = g4d; g4d = ax;
+        }
+        // 64 signals x 16 samples transposed through LDS: a store instruction writes eight 128-byte runs
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tile[lane][k] = y[k];
+        wave_lds_fence();
+        double2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const double* t = &tile[r * 8 + (lane >> 3)][2 * (lane & 7)];
+          v[r] = make_double2(t[0], t[1]);
+        }
+        const size_t at = (size_t)bl * kFbFrame + 16 * kc + 2 * (lane & 7);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) *reinterpret_cast<d2u*>(out_row[r] + at) = d2u{v[r].x, v[r].y};
+        wave_lds_fence();
+      };
+      // the first chunk on its own: the loop's entry then has the same operations in flight as its back edge (four
+      // loads, then eight stores), and the compiler waits for exactly the loads
+      fast_chunk(0, true);
+#pragma unroll 1
+      for (int kc = 1; kc < kFbFrame / 16; ++kc) fast_chunk(kc, false);
+      above = smax >= (float)(200. / 32768);
+    } else {
+    float sum = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;   // |x| of the last five samples
     for (int kc = 0; kc < kFbFrame / 16; ++kc) {
       const unsigned c = bl * (kFbFrame / 16) + kc;
       // this chunk (requested a chunk ago) into LDS, out again by channel; the next one requested
@@ -222,20 +326,18 @@ __global__ __launch_bounds__(64 * kHpWaves) void fb_hp_kernel(FbFrontArgs a, uns
       // 64 x 8 transpose through LDS: each store instruction writes 64-byte runs
 #pragma unroll
       for (int j = 0; j < 8; ++j) tile[lane][j] = y[j];
-      // the workgroup is ONE wave: LDS is in program order, no barrier needed -- and
+      // the workgroup's waves are independent: LDS is in program order, no barrier needed -- and
       // __syncthreads() would drain the prefetched loads and the stores (vmcnt(0)) every 8 samples
       wave_lds_fence();
+      double v[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int src = r * 8 + (lane >> 3);
-        // the source lane's row and block count (its own mapping under broker launches)
-        const unsigned row_s = (unsigned)__shfl((int)state_idx, src, 64);
-        const unsigned nb_s = (unsigned)__shfl((int)nb_mine, src, 64);
-        if (bl < nb_s)
-          rows[(size_t)row_s * row_len + kFbRing + (size_t)bl * kFbFrame + k0 + (lane & 7)] = tile[src][lane & 7];
-      }
+      for (int r = 0; r < 8; ++r) v[r] = tile[r * 8 + (lane >> 3)][lane & 7];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (bl < nb_s[r]) out_row[r][(size_t)bl * kFbFrame + k0 + (lane & 7)] = v[r];
       wave_lds_fence();
       }
+    }
     }
     if (mine && sig == 0)
       a.records[((size_t)(pair * a.blocks_per_launch + bl) * a.channels + chan) * kFbRecDoubles + kFbRecFlags] =

@@ -292,6 +292,45 @@ def test_empty_and_tiny_pairs_inside_a_batch(gpu, advanced, fir_mode):
         np.testing.assert_allclose(g["movs"][fin], e["movs"][:len(g["movs"])][fin], rtol=gpu.tol("movs", advanced), atol=1e-9)
 
 
+def _threshold_outro_pair(p, n, quiet_blocks, reached):
+    """A stereo pair whose last `quiet_blocks` 192-sample blocks are far below the data-boundary threshold, except for
+    one block -- a different one, at a different position and in a different channel for every p -- that is silent but
+    for a run of five samples of 40 / 32768: five of them sum to 200 / 32768 exactly, the threshold (`reached`), or of
+    one float ulp less.  Blocks below the threshold are accumulated tentatively and count only if a later one reaches
+    it (gstpeaq.c:971-979, movaccum.c:305-340), so that run decides how much of the quiet end enters the averages."""
+    a = np.float32(40.0 / 32768)
+    r, t = synth_np.pair(9000 + p, 2, n)
+    g = np.random.default_rng(77 + p)
+    q = quiet_blocks * 192
+    r[n - q:] = (g.uniform(-0.3, 0.3, (q, 2)) * a).astype(np.float32)
+    t[n - q:] = (r[n - q:] + g.uniform(-0.05, 0.05, (q, 2)) * a).astype(np.float32)
+    blk, at, ch = quiet_blocks - 12 + (5 * p) % 11, 5 + (37 * p) % 180, p & 1
+    s = n - q + blk * 192
+    r[s: s + 192] = 0
+    t[s: s + 192] = 0
+    r[s + at: s + at + 5, ch] = a if reached else np.float32(a * np.float32(1 - 2.0 ** -23))
+    return r, t
+
+
+def test_advanced_data_boundary_at_the_threshold_in_full_waves(gpu, fir_mode):
+    """The boundary detector of the 192-sample blocks (gstpeaq.c:1081-1099) sits in the high-pass walk, whose
+    straight-line blocks need a full wave of 64 signals -- the single-pair stage tests above never give it one.  32
+    stereo pairs put the threshold itself to the test (see _threshold_outro_pair), every other one an ulp below it."""
+    n, pairs, quiet = 192 * 150, 32, 40
+    inputs = [_threshold_outro_pair(p, n, quiet, reached=p % 2 == 0) for p in range(pairs)]
+    got = gpu.run_batch(inputs, 1, 2)
+    for p in range(pairs):
+        e = orc.run_pair(1, *inputs[p])["movs"][:5]
+        g = got[p]["movs"][:5]
+        assert np.array_equal(np.isnan(g), np.isnan(e)), (p, g, e)
+        fin = ~np.isnan(e)
+        np.testing.assert_allclose(g[fin], e[fin], rtol=gpu.tol("movs"), atol=1e-9, err_msg=f"pair {p}")
+    # the test has teeth: the ulp decides
+    e0 = orc.run_pair(1, *_threshold_outro_pair(0, n, quiet, True))["movs"][:5]
+    e1 = orc.run_pair(1, *_threshold_outro_pair(0, n, quiet, False))["movs"][:5]
+    assert np.isfinite(e0).all() and not np.allclose(e0, e1, rtol=1e-3, atol=0, equal_nan=True)
+
+
 @pytest.mark.parametrize("advanced", [0, 1])
 def test_playback_level_matches_reference_goldens(gpu, advanced, fir_mode):
     """playback_level 60 .. 130 dB SPL through batch run, session and broker vs the real element"""
