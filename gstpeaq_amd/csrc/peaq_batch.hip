@@ -72,7 +72,7 @@ extern "C" size_t peaq_batch_workspace_bytes(int advanced, int channels, int n_p
 static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n_pairs, const float* d_ref,
                                const float* d_test, size_t pair_stride, const uint32_t* d_nref,
                                const uint32_t* d_ntest, uint32_t n_uniform, const uint32_t* d_nblocks,
-                               uint32_t max_blocks, hipStream_t stream) {
+                               uint32_t max_blocks, hipStream_t stream, hipEvent_t bank_gate) {
     // ---- filter-bank path: blocks of 192 samples (gstpeaq.c:648-652) ------------------
     const unsigned n_signals = (unsigned)n_pairs * channels * 2;
     const unsigned bc = fb_blocks_per_chunk(n_pairs, channels, max_blocks);
@@ -153,6 +153,7 @@ static int run_filterbank_path(peaq_ctx* c, int channels, double level_db, int n
         HIP_TRY(hipEventRecord(e_hp, s_hp));
         HIP_TRY(hipStreamWaitEvent(s_bank, e_hp, 0));
       }
+      if (chunk == 0 && bank_gate) HIP_TRY(hipStreamWaitEvent(s_bank, bank_gate, 0));   // (batch_run_locked: the FFT path's head)
       HIP_TRY(hipEventRecord(e0, s_bank));
       HIP_TRY(launch_fb_bank(ff, n_pairs, s_bank));
       HIP_TRY(hipEventRecord(e1, s_bank));
@@ -283,23 +284,28 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
 
   HIP_TRY(hipEventRecord(c->batch_begin, stream));
   HIP_TRY(launch_state_init(c->state.as<PairState>(), advanced, n_pairs, stream));
-  hipEvent_t fb_done = nullptr;
+  hipEvent_t fb_done = nullptr, forked = nullptr;
   c->fb_last_bank_begin = c->fb_last_bank_end = nullptr;
-  if (advanced && max_blocks > 0) {
+  const bool with_fb = advanced && max_blocks > 0;
+  if (with_fb) {
     // the filter-bank path (its own ear model, accumulators 0, 1, 4) is independent of the FFT
     // path (accumulators 2, 3): it runs on a third stream from here on and joins at the end
-    hipEvent_t forked = c->next_event();
+    forked = c->next_event();
     if (!forked) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(forked, stream));
     HIP_TRY(hipStreamWaitEvent(c->aux2, forked, 0));
+  }
+  // (its launches are issued further down, between the FFT path's head and the rest of its chunks)
+  auto issue_filterbank_path = [&](hipEvent_t bank_gate) -> int {
     hipStream_t s_fb = PEAQ_DEV_SERIAL_KERNELS ? stream : c->aux2;
     const int rc = run_filterbank_path(c, channels, level_db, n_pairs, d_ref, d_test, pair_stride, d_nref, d_ntest,
-                                       n_uniform, d_nblocks, max_blocks, s_fb);
+                                       n_uniform, d_nblocks, max_blocks, s_fb, bank_gate);
     if (rc != PEAQ_OK) return rc;
     fb_done = c->next_event();
     if (!fb_done) return fail(PEAQ_ERR_DEVICE, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(fb_done, s_fb));
-  }
+    return PEAQ_OK;
+  };
 
   FrontendArgs fa{};
   fa.cfg = c->settings;
@@ -337,7 +343,7 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
   // millions of workgroups) runs on the caller's stream while the back end of chunk i
   // (one workgroup per pair, latency bound) runs on the context's second stream; the
   // per-frame records are double buffered.
-  hipEvent_t back_done[2] = {nullptr, nullptr};
+  hipEvent_t back_done[2] = {nullptr, nullptr}, head_done = nullptr;
   unsigned chunk = 0;
   // Advanced version: the last chunks of the FFT path are held back until the filter-bank path's last bank launch
   // is through.  An advanced pass ends with that launch's back end alone on the device (one workgroup per pair walking
@@ -348,9 +354,18 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
   const unsigned n_chunks = fc ? (max_frames + fc - 1) / fc : 0u;   // (a pair of two empty signals has no frames at all)
   static const int defer_env = [] { const char* e = std::getenv("PEAQ_AMD_ADV_DEFER"); return e && *e ? std::atoi(e) : -1; }();
   static const bool defer_begin = [] { const char* e = std::getenv("PEAQ_AMD_ADV_DEFER"); return e && std::strchr(e, 'b'); }();
-  const unsigned defer = (!advanced || !c->fb_last_bank_end || PEAQ_DEV_SERIAL_KERNELS) ? 0u
-                         : std::min<unsigned>(defer_env >= 0 ? (unsigned)defer_env : 2u, n_chunks > 4 ? n_chunks - 4 : 0u);
-  for (uint32_t f0 = 0; f0 < max_frames; f0 += fc, ++chunk) {
+  const bool fb_piped = with_fb && !PEAQ_DEV_SERIAL_KERNELS;
+  const unsigned defer = !fb_piped ? 0u : std::min<unsigned>(defer_env >= 0 ? (unsigned)defer_env : 2u, n_chunks > 4 ? n_chunks - 4 : 0u);
+  // ... and with the FP64 bank the FIRST bank launch waits for the front end of all chunks before those (the head).
+  // Two workgroups of fb_bank_kernel<MfmaF64> fill a CU's registers and LDS: whatever runs beside it does so in place
+  // of one of them, and then neither kernel has the waves to cover its latencies -- beside the first bank launch a chunk
+  // of frontend_kernel<55> took 33 .. 39 ms, alone it takes 6.6 (profiles/r05_timeline_adv.txt: before / after).  The
+  // first two walks of the high-pass filter, which the bank has to wait for anyway, run beside the head.  Measured:
+  // 5.38 M -> 5.47 M; the reduced-precision engine, whose bank kernel leaves room beside it, loses 0.6 % and keeps
+  // the old order.  PEAQ_AMD_ADV_HEAD=<chunks> (development): other counts.
+  static const int head_env = [] { const char* e = std::getenv("PEAQ_AMD_ADV_HEAD"); return e && *e ? std::atoi(e) : -1; }();
+  const unsigned head = !fb_piped ? 0u : std::min<unsigned>(head_env >= 0 ? (unsigned)head_env : (c->fir_fp64 == PEAQ_FIR_F64 ? n_chunks : 0u), n_chunks - defer);
+  auto issue_chunk = [&](uint32_t f0) -> int {
     const unsigned nf = std::min<uint32_t>(fc, max_frames - f0);
     if (defer && chunk == n_chunks - defer)
       HIP_TRY(hipStreamWaitEvent(stream, defer_begin ? c->fb_last_bank_begin : c->fb_last_bank_end, 0));
@@ -372,8 +387,23 @@ static int batch_run_locked(peaq_ctx* c, int advanced, int channels, double leve
     if (!PEAQ_DEV_SKIP_BACKEND) HIP_TRY(launch_backend(ba, n_pairs, c->aux));
     HIP_TRY(hipEventRecord(e3, c->aux));
     back_done[chunk & 1] = e3;
+    head_done = e1;
     c->spans.push_back({e0, e1, 0});
     c->spans.push_back({e2, e3, 1});
+    return PEAQ_OK;
+  };
+  uint32_t f0 = 0;
+  for (; chunk < head; f0 += fc, ++chunk) {
+    const int rc = issue_chunk(f0);
+    if (rc != PEAQ_OK) return rc;
+  }
+  if (with_fb) {
+    const int rc = issue_filterbank_path(head ? head_done : nullptr);
+    if (rc != PEAQ_OK) return rc;
+  }
+  for (; f0 < max_frames; f0 += fc, ++chunk) {
+    const int rc = issue_chunk(f0);
+    if (rc != PEAQ_OK) return rc;
   }
   for (int i = 0; i < 2; ++i)
     if (back_done[i]) HIP_TRY(hipStreamWaitEvent(stream, back_done[i], 0));

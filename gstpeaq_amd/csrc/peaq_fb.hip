@@ -64,18 +64,35 @@ struct HpWalk {
 #define PEAQ_HP_WAVES 4
 #endif
 constexpr int kHpWaves = PEAQ_HP_WAVES;
-// (at most 256 registers: a wave of this kernel shares its SIMD with one of the bank kernel's, 240 of the 512)
-__global__ __launch_bounds__(64 * kHpWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void fb_hp_kernel(FbFrontArgs a,
-                                                                                                       unsigned n_signals) {
+// The boundary detector of gstpeaq.c:1083-1096 (FLOAT running sum over five |x|, tested from i = 5 on) in the same
+// arithmetic with less of it: |x| as a double is the absolute value of the sample's double, the history is kept
+// converted (zeros at a block's start: i < 5 adds |x| itself), and the threshold 200 / 32768 is a float -- so
+// "sum >= threshold at some i >= 5" is a float maximum compared once per block.
+struct BoundaryDetector {
+  double sumd = 0., g0 = 0., g1 = 0., g2 = 0., g3 = 0., g4 = 0.;
+  float smax = 0.f;
+  __device__ __forceinline__ void step(double xd, bool is_sample_4) {
+    const double ax = fabs(xd);
+    sumd = (double)(float)(sumd + (ax - g0));
+    smax = fmaxf(smax, (float)sumd);                 // (a NaN sum is never "reached", like the comparison)
+    if (is_sample_4) smax = 0.f;
+    g0 = g1; g1 = g2; g2 = g3; g3 = g4; g4 = ax;
+  }
+  __device__ __forceinline__ int above() const { return smax >= (float)(200. / 32768); }
+};
+
+__global__ __launch_bounds__(64 * kHpWaves) void fb_hp_kernel(FbFrontArgs a, unsigned n_signals) {
   __shared__ double tiles[kHpWaves][64][17];        // per wave: [signal in wave][16 samples], padded
   __shared__ float inbufs[kHpWaves][64 * 18];
   const int lane = threadIdx.x & 63;
   double (*tile)[17] = tiles[threadIdx.x >> 6];
   float* inbuf = inbufs[threadIdx.x >> 6];
   const unsigned g0 = blockIdx.x * (64 * kHpWaves) + (threadIdx.x & ~63u);
-  const unsigned g = g0 + lane;
-  const bool live = g < n_signals;
-  const unsigned gg = live ? g : n_signals - 1;
+  if (g0 >= n_signals) return;                       // (the waves of a workgroup are independent: no barrier below)
+  // A wave with fewer than 64 signals left: the spare lanes walk the LAST signal too -- the same loads, the same
+  // arithmetic, the same stores of the same values to the same addresses in the same instructions -- so that every
+  // wave is a full one and its blocks can take the straight-line path below (a single pair is four signals).
+  const unsigned gg = min(g0 + lane, n_signals - 1);
   const int sig = gg & 1;
   const int chan = (gg >> 1) % a.channels;
   const unsigned pair = gg / (2 * a.channels);
@@ -94,8 +111,8 @@ __global__ __launch_bounds__(64 * kHpWaves) __attribute__((amdgpu_waves_per_eu(2
     prev_blocks = w.prev_blocks;
     first = w.block0 == 0;
     state_idx = (w.slot * a.channels + chan) * 2 + sig;
-    if (live) nb_mine = w.n_blocks;
-  } else if (live && n_blocks > a.block0) {
+    nb_mine = w.n_blocks;
+  } else if (n_blocks > a.block0) {
     nb_mine = min(a.blocks_per_launch, n_blocks - a.block0);
   }
   double* __restrict__ my_row = rows + (size_t)state_idx * row_len;
@@ -123,8 +140,7 @@ __global__ __launch_bounds__(64 * kHpWaves) __attribute__((amdgpu_waves_per_eu(2
     }
   }
   HpWalk w{st->hp[0], st->hp[1], st->hp[2], st->hp[3], st->hp[4], st->hp[5]};
-  HpWalk fin = w;
-  double peak = 0., peak_fin = 0.;                   // largest |filtered sample| of this signal's blocks
+  double peak = 0.;                                  // largest |filtered sample| of this signal's blocks
 
   // The input: CHUNKS of 16 samples, one chunk ahead of their use (the walk is a chain of dependent FP64 operations:
   // the loads must never be waited for).  A chunk of a (pair, signal) row is 64 C contiguous bytes (C channels
@@ -137,9 +153,8 @@ __global__ __launch_bounds__(64 * kHpWaves) __attribute__((amdgpu_waves_per_eu(2
   const int kInStride = C == 2 ? 34 : 18;            // floats per row in LDS: 16 C samples + padding (8-byte rows; the
                                                      // channels' reads fall on different banks, two-way at worst)
   const int ld_row = lane / C, ld_piece0 = 4 * (lane % C);            // the row this lane fetches for, its first piece
-  const unsigned ld_gg = g0 + (unsigned)((ld_row >> 1) * C) * 2u + (unsigned)(ld_row & 1);   // that row's channel-0 signal
-  const bool ld_live = ld_gg < n_signals;
-  const unsigned ld_pair = (ld_live ? ld_gg : n_signals - 1) / (2 * C);
+  const unsigned ld_gg = min(g0 + (unsigned)((ld_row >> 1) * C) * 2u + (unsigned)(ld_row & 1), n_signals - 1);   // that row's channel-0 signal
+  const unsigned ld_pair = ld_gg / (2 * C);          // (spare rows: the last pair's)
   const float* __restrict__ ld_base = ((ld_row & 1) ? a.test : a.ref) + (size_t)ld_pair * a.pair_stride * C;
   const long long ld_len = (long long)a.pair_stride * C;              // floats in a row
   // sample index (in its row) of sample 0 of the launch's block bl: the same for every pair (broker launches:
@@ -147,21 +162,13 @@ __global__ __launch_bounds__(64 * kHpWaves) __attribute__((amdgpu_waves_per_eu(2
   const long long s_first = (long long)(blk0 - origin) * kFbFrame;
   const long long ld_s0 = s_first + ((ld_row & 1) ? a.off_test : a.off_ref);
   const long long my_s0 = s_first + off;
-  // fast chunks: inside every lane's signal and block count (no zero padding, gstpeaq.c:733-738, to apply)
-  unsigned n_min = live ? n_sig : 0xFFFFFFFFu, nb_min = live ? nb_mine : 0u;
-  if (!live) nb_min = 0;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    n_min = min(n_min, (unsigned)__shfl_xor((int)n_min, d, 64));
-    nb_min = min(nb_min, (unsigned)__shfl_xor((int)nb_min, d, 64));
-  }
   const unsigned n_chunks = nb_max * (kFbFrame / 16);
   auto load_chunk = [&](unsigned c, f4u (&v)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long f = (ld_s0 + 16ll * c) * C + 4 * (ld_piece0 + j);    // first float of the piece in its row
       f4u t = {0.f, 0.f, 0.f, 0.f};
-      if (ld_live && c < n_chunks && f >= 0) {
+      if (c < n_chunks && f >= 0) {
         if (f + 4 <= ld_len) {
           t = *reinterpret_cast<const f4u*>(ld_base + f);
         } else {                                                        // the row ends inside the piece
@@ -176,37 +183,47 @@ __global__ __launch_bounds__(64 * kHpWaves) __attribute__((amdgpu_waves_per_eu(2
   f4u nxt[4];
   load_chunk(0, nxt);
   const int in_at = (2 * (lane / (2 * C)) + sig) * kInStride + chan;       // this lane's first sample of a chunk in LDS
+  auto chunk_to_lds = [&]() {                        // the chunk requested a chunk ago: into LDS, to be read by channel
+    float* dst = inbuf + ld_row * kInStride + 4 * ld_piece0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      reinterpret_cast<float2*>(dst + 4 * j)[0] = make_float2(nxt[j][0], nxt[j][1]);
+      reinterpret_cast<float2*>(dst + 4 * j)[1] = make_float2(nxt[j][2], nxt[j][3]);
+    }
+    // the workgroup's waves are independent: LDS is in program order, no barrier needed -- and __syncthreads() would
+    // drain the prefetched loads and the stores (vmcnt(0))
+    wave_lds_fence();
+  };
 
-  // Where the transposed tiles go: store instruction r carries the signals 8 r + lane / 8 (their rows and block
-  // counts fetched once -- as shuffles in the loop they were two LDS round trips in front of every store)
-  double* out_row[8];
-  unsigned nb_s[8];
+  // Where the transposed tiles go: store instruction r carries sixteen samples of the signals 8 r + lane / 8 (their
+  // rows and block counts fetched once -- as shuffles in the loop they were two LDS round trips in front of every store)
+  unsigned row_s[8], nb_s[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int src = r * 8 + (lane >> 3);
-    out_row[r] = rows + (size_t)(unsigned)__shfl((int)state_idx, src, 64) * row_len + kFbRing;
+    row_s[r] = (unsigned)__shfl((int)state_idx, src, 64);
     nb_s[r] = (unsigned)__shfl((int)nb_mine, src, 64);
   }
+  double* __restrict__ const out0 = rows + kFbRing + 2 * (lane & 7);      // + row * row_len + the sample's index
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 
-  // FAST blocks: all 64 lanes live, the block inside every lane's signal and block count, and the sixteen-byte
-  // pieces of its chunks and of the chunk after it inside their rows.  Such a block is straight-line code -- no
-  // bounds checks, no zero padding, unconditional loads and stores -- and that is what makes it fast: a wave's vector
-  // memory operations return through ONE in-order counter, and with loads or stores under lane masks the compiler
-  // has to wait for the counter to reach zero wherever it needs a load's data, i.e. for the acknowledgement of every
-  // store of the chunk before (measured: the walk took 410 cycles per sample, 145 of them instructions).
+  // STRAIGHT-LINE blocks: the block inside every lane's signal and block count, and the sixteen-byte pieces of its
+  // chunks and of the chunk after it inside their rows.  Such a block has no bounds checks, no zero padding,
+  // unconditional loads and stores -- and that is what makes it fast: a wave's vector memory operations return
+  // through ONE in-order counter, and with loads or stores under lane masks the compiler has to wait for the counter
+  // to reach zero wherever it needs a load's data, i.e. for the acknowledgement of every store of the chunk before
+  // (measured: the walk took 410 cycles per sample, 145 of them instructions).
   unsigned f_lo, f_hi;
   {
-    const long long kBig = 1ll << 40;
     auto ceil_div = [](long long x, long long d) { return x <= 0 ? 0ll : (x + d - 1) / d; };
     auto floor_div = [](long long x, long long d) { return x <= 0 ? 0ll : x / d; };
     // chunks [c_lo, c_hi) of the launch lie inside this lane's signal; chunks [l_lo, l_hi) inside its loader row
     const long long c_lo = ceil_div(-my_s0, 16), c_hi = min((long long)nb_mine * (kFbFrame / 16), floor_div((long long)n_sig - my_s0, 16));
     const long long l_lo = ceil_div(-ld_s0, 16), l_hi = floor_div((long long)a.pair_stride - ld_s0, 16);
     // block bl: chunks 12 bl .. 12 bl + 11 computed, 12 bl + 1 .. 12 bl + 12 loaded
-    long long lo = max(ceil_div(c_lo, 12), ceil_div(l_lo - 1, 12));
-    long long hi = min(floor_div(c_hi, 12), l_hi >= 13 ? (l_hi - 13) / 12 + 1 : 0ll);
-    if (!live || !ld_live) hi = 0;
-    unsigned ulo = (unsigned)min(lo, kBig >> 12), uhi = (unsigned)min(hi, kBig >> 12);
+    const long long lo = max(ceil_div(c_lo, 12), ceil_div(l_lo - 1, 12));
+    const long long hi = min(floor_div(c_hi, 12), l_hi >= 13 ? (l_hi - 13) / 12 + 1 : 0ll);
+    unsigned ulo = (unsigned)min(lo, 1ll << 28), uhi = (unsigned)min(hi, 1ll << 28);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
       ulo = max(ulo, (unsigned)__shfl_xor((int)ulo, d, 64));
@@ -216,32 +233,19 @@ __global__ __launch_bounds__(64 * kHpWaves) __attribute__((amdgpu_waves_per_eu(2
     f_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)uhi);
   }
   const float* __restrict__ ld_ptr = ld_base + ld_s0 * C + 4 * ld_piece0;   // (never dereferenced outside the row)
-  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 
   for (unsigned bl = 0; bl < nb_max; ++bl) {
     const bool mine = bl < nb_mine;
-    int above = 0;
+    BoundaryDetector det;
     if (bl >= f_lo && bl < f_hi) {
-      // ---- fast block ----
-      // The detector of gstpeaq.c:1083-1096 in the same arithmetic with less of it: |x| as a double is the absolute
-      // value of the sample's double, the history is kept converted, and the threshold 200 / 32768 is a float, so
-      // "sum >= threshold at some i >= 5" is a float maximum compared once per block.
-      double sumd = 0., g0d = 0., g1d = 0., g2d = 0., g3d = 0., g4d = 0.;
-      float smax = 0.f;
       auto fast_chunk = [&](const int kc, const bool block_head) __attribute__((always_inline)) {
         const unsigned c = bl * (kFbFrame / 16) + kc;
         float xc[16];
+        chunk_to_lds();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) xc[k] = inbuf[in_at + k * C];
+        wave_lds_fence();
         {
-          float* dst = inbuf + ld_row * kInStride + 4 * ld_piece0;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            reinterpret_cast<float2*>(dst + 4 * j)[0] = make_float2(nxt[j][0], nxt[j][1]);
-            reinterpret_cast<float2*>(dst + 4 * j)[1] = make_float2(nxt[j][2], nxt[j][3]);
-          }
-          wave_lds_fence();
-#pragma unroll
-          for (int k = 0; k < 16; ++k) xc[k] = inbuf[in_at + k * C];
-          wave_lds_fence();
           const float* __restrict__ src = ld_ptr + (size_t)(16u * (c + 1)) * C;
 #pragma unroll
           for (int j = 0; j < 4; ++j) nxt[j] = *reinterpret_cast<const f4u*>(src + 4 * j);
@@ -252,11 +256,7 @@ __global__ __launch_bounds__(64 * kHpWaves) __attribute__((amdgpu_waves_per_eu(2
           const double xd = (double)xc[k];
           y[k] = w.step(xd * a.level_factor);
           peak = fmax(peak, fabs(y[k]));
-          const double ax = fabs(xd);
-          sumd = (double)(float)(sumd + (ax - g0d));                     // (the history starts as zeros: i < 5 adds |x| itself)
-          smax = fmaxf(smax, (float)sumd);
-          if (block_head && k == 4) smax = 0.f;                          // tested from i = 5 on
-          g0d = g1d; g1d = g2d; g2d = g3d; g3d = g4d; g4d = ax;
+          det.step(xd, block_head && k == 4);
         }
         // 64 signals x 16 samples transposed through LDS: a store instruction writes eight 128-byte runs
 #pragma unroll
@@ -268,9 +268,9 @@ __global__ __launch_bounds__(64 * kHpWaves) __attribute__((amdgpu_waves_per_eu(2
           const double* t = &tile[r * 8 + (lane >> 3)][2 * (lane & 7)];
           v[r] = make_double2(t[0], t[1]);
         }
-        const size_t at = (size_t)bl * kFbFrame + 16 * kc + 2 * (lane & 7);
+        const size_t at = (size_t)bl * kFbFrame + 16 * kc;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) *reinterpret_cast<d2u*>(out_row[r] + at) = d2u{v[r].x, v[r].y};
+        for (int r = 0; r < 8; ++r) *reinterpret_cast<d2u*>(out0 + ((size_t)row_s[r] * row_len + at)) = d2u{v[r].x, v[r].y};
         wave_lds_fence();
       };
       // the first chunk on its own: the loop's entry then has the same operations in flight as its back edge (four
@@ -278,84 +278,51 @@ __global__ __launch_bounds__(64 * kHpWaves) __attribute__((amdgpu_waves_per_eu(2
       fast_chunk(0, true);
 #pragma unroll 1
       for (int kc = 1; kc < kFbFrame / 16; ++kc) fast_chunk(kc, false);
-      above = smax >= (float)(200. / 32768);
     } else {
-    float sum = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;   // |x| of the last five samples
-    for (int kc = 0; kc < kFbFrame / 16; ++kc) {
-      const unsigned c = bl * (kFbFrame / 16) + kc;
-      // this chunk (requested a chunk ago) into LDS, out again by channel; the next one requested
-      float xc[16];
-      {
-        float* dst = inbuf + ld_row * kInStride + 4 * ld_piece0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          reinterpret_cast<float2*>(dst + 4 * j)[0] = make_float2(nxt[j][0], nxt[j][1]);
-          reinterpret_cast<float2*>(dst + 4 * j)[1] = make_float2(nxt[j][2], nxt[j][3]);
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) xc[k] = inbuf[in_at + k * C];
-        wave_lds_fence();
+      // ---- any other block (a signal's first and last, ragged batches): sample by sample out of LDS.  Rolled, so
+      // that this path costs the kernel neither registers nor instruction cache; the next sample is requested while
+      // the current one is worked on ----
+#pragma unroll 1
+      for (int kc = 0; kc < kFbFrame / 16; ++kc) {
+        const unsigned c = bl * (kFbFrame / 16) + kc;
+        chunk_to_lds();
+        float xn = inbuf[in_at];
         load_chunk(c + 1, nxt);
-        const long long s_c = my_s0 + 16ll * c;
-        if (!(bl < nb_min && s_c + 16 <= (long long)n_min)) {            // (wave-uniform) zero padding / idle lanes
-#pragma unroll
-          for (int k = 0; k < 16; ++k) xc[k] = (mine && s_c + k >= 0 && s_c + k < (long long)n_sig) ? xc[k] : 0.f;
+        const long long s_c = my_s0 + 16ll * c;      // zero padding (gstpeaq.c:733-738) and idle lanes
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) {
+          const float xr = xn;
+          xn = inbuf[in_at + min(k + 1, 15) * C];
+          const double xd = (double)((mine && s_c + k >= 0 && s_c + k < (long long)n_sig) ? xr : 0.f);
+          const double y = w.step(xd * a.level_factor);
+          peak = fmax(peak, fabs(y));
+          det.step(xd, kc == 0 && k == 4);
+          tile[lane][k] = y;
         }
-      }
+        wave_lds_fence();
+        const size_t at = (size_t)bl * kFbFrame + 16 * kc;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-      const int k0 = 16 * kc + 8 * half;
-      double y[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = k0 + j;
-        const float xv = xc[8 * half + j];
-        y[j] = w.step((double)xv * a.level_factor);
-        peak = fmax(peak, fabs(y[j]));
-        // gstpeaq.c:1083-1096: FLOAT running sum, tested from i = 5 on
-        const float ax = fabsf(xv);
-        if (k < 5) {
-          sum = (float)((double)sum + (double)ax);
-        } else {
-          sum = (float)((double)sum + ((double)ax - (double)h0));
-          above |= ((double)sum >= 200. / 32768);
+        for (int r = 0; r < 8; ++r) {
+          const double* t = &tile[r * 8 + (lane >> 3)][2 * (lane & 7)];
+          const d2u v = {t[0], t[1]};
+          if (bl < nb_s[r]) *reinterpret_cast<d2u*>(out0 + ((size_t)row_s[r] * row_len + at)) = v;
         }
-        h0 = h1; h1 = h2; h2 = h3; h3 = h4; h4 = ax;
+        wave_lds_fence();
       }
-      // 64 x 8 transpose through LDS: each store instruction writes 64-byte runs
-#pragma unroll
-      for (int j = 0; j < 8; ++j) tile[lane][j] = y[j];
-      // the workgroup's waves are independent: LDS is in program order, no barrier needed -- and
-      // __syncthreads() would drain the prefetched loads and the stores (vmcnt(0)) every 8 samples
-      wave_lds_fence();
-      double v[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = tile[r * 8 + (lane >> 3)][lane & 7];
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-        if (bl < nb_s[r]) out_row[r][(size_t)bl * kFbFrame + k0 + (lane & 7)] = v[r];
-      wave_lds_fence();
-      }
-    }
     }
     if (mine && sig == 0)
       a.records[((size_t)(pair * a.blocks_per_launch + bl) * a.channels + chan) * kFbRecDoubles + kFbRecFlags] =
-          (double)above;
-    // the wave walks on (with zero input) until its longest signal is done: keep the state as it
-    // was after this signal's own last block
+          (double)det.above();
+    // the wave walks on (with zero input) until its longest signal is done: the state goes home as it
+    // is after this signal's own last block
     if (bl + 1 == nb_mine) {
-      fin = w;
-      peak_fin = peak;
+      st->hp[0] = w.x1; st->hp[1] = w.x2; st->hp[2] = w.y1a; st->hp[3] = w.y2a; st->hp[4] = w.y1b;
+      st->hp[5] = w.y2b;
+      const int slot = a.launch_idx % 3;
+      st->peak_slot[slot][0] = peak;
+      st->peak_slot[slot][1] = peak_head;              // the window's head: the last 1456 filtered samples before this launch
+      st->peak_last = peak;
     }
-  }
-  if (nb_mine > 0) {
-    st->hp[0] = fin.x1; st->hp[1] = fin.x2; st->hp[2] = fin.y1a; st->hp[3] = fin.y2a; st->hp[4] = fin.y1b;
-    st->hp[5] = fin.y2b;
-    const int slot = a.launch_idx % 3;
-    st->peak_slot[slot][0] = peak_fin;
-    st->peak_slot[slot][1] = peak_head;                // the window's head: the last 1456 filtered samples before this launch
-    st->peak_last = peak_fin;
   }
 }
 
