@@ -62,11 +62,16 @@ def test_default_fp64_filter_bank_fits_two_waves_per_simd_without_scratch(fb_met
     assert bank["vgpr_count"] + hp["vgpr_count"] <= 512, (bank, hp)
 
 
-def test_opt_in_f16x3_filter_bank_leaves_room_for_the_high_pass_walk(fb_meta):
+def test_opt_in_f16x3_filter_bank_and_the_high_pass_walk(fb_meta):
+    """Until round 5 the walk (102 registers, 28 ms per launch: the bank launch waited for it) had to fit beside TWO
+    waves of this bank kernel.  The walk of round 5 takes 17.6 ms and whatever registers the compiler likes (about 200:
+    held to 168 it spills into its block loop and the pass measures 0.4 % slower, profiles/r05_ab_adv.txt); what
+    has to hold is one wave of each on a SIMD, two workgroups of the bank per CU, nothing in scratch."""
     bank, hp = find(fb_meta, "fb_bank_kernel_h3"), find(fb_meta, "fb_hp_kernel")
-    assert bank["vgpr_spill_count"] == 0 and hp["vgpr_spill_count"] == 0
-    assert 2 * bank["vgpr_count"] + hp["vgpr_count"] <= 512, (bank, hp)
+    assert bank["vgpr_spill_count"] == 0 and hp["vgpr_spill_count"] == 0 and hp["private_segment_fixed_size"] == 0
+    assert 2 * bank["vgpr_count"] <= 512 and bank["vgpr_count"] + hp["vgpr_count"] <= 512, (bank, hp)
     assert 2 * bank["group_segment_fixed_size"] <= 160 * 1024          # two workgroups per CU
+    assert bank["group_segment_fixed_size"] + hp["group_segment_fixed_size"] <= 160 * 1024, (bank, hp)
 
 
 def test_three_waves_per_simd_for_the_fft_path(tmp_path):
