@@ -8,7 +8,7 @@
 //                   the 192-sample block (gstpeaq.c:971-972,1081-1099) with the
 //                   reference's float running sum, bit for bit.  Output: the filtered
 //                   signal in FP64, one row per signal, staged through LDS so that the
-//                   stores are 64-byte runs.
+//                   stores are 128-byte runs.
 //  fb_bank_kernel   one WORKGROUP of four waves per (pair, channel, signal), walking the
 //                   chunk in tiles of 60 sub-samples (= 10 blocks of 192 samples).  The
 //                   window of the filtered signal sits in LDS; the 40 complex FIR filters
@@ -58,8 +58,9 @@ struct HpWalk {
 // Workgroups of kHpWaves INDEPENDENT waves.  Beside the FP64 engine's bank kernel -- whose two workgroups fill a CU's
 // registers and LDS -- a workgroup of this kernel takes the place of one of them for as long as the walk lasts: in
 // workgroups of one wave the dispatcher spreads a 4096-pair batch's 256 waves over 256 CUs, in workgroups of four
-// (one wave per SIMD) over 64.  Measured, 4096 pairs, advanced pass of the FP64 engine: 1 wave 413-416 ms, 2: 409,
-// 4: 404, 8: 418 (the walk itself then takes longer than the bank launch it has to finish beside).
+// (one wave per SIMD) over 64.  Measured, 4096 pairs, advanced pass of the FP64 engine: round 4 (the walk 28 ms
+// alone) 1 wave 413-416 ms, 2: 409, 4: 404, 8: 418; round 5 (17 ms, two of the three walks beside the FFT path's
+// head) 1: 355, 2: 353, 4: 350, 8: 353 (profiles/r05_ab_adv.txt).
 #ifndef PEAQ_HP_WAVES
 #define PEAQ_HP_WAVES 4
 #endif
