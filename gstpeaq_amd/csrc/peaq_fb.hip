@@ -116,27 +116,44 @@ __global__ __launch_bounds__(64 * kHpWaves) void fb_hp_kernel(FbFrontArgs a, uns
   } else if (n_blocks > a.block0) {
     nb_mine = min(a.blocks_per_launch, n_blocks - a.block0);
   }
-  double* __restrict__ my_row = rows + (size_t)state_idx * row_len;
   FbSignalState* __restrict__ st = a.fbstate + state_idx;
 
   unsigned nb_max = nb_mine;                         // wave-uniform loop bound
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) nb_max = max(nb_max, (unsigned)__shfl_xor((int)nb_max, d, 64));
 
-  // history: the newest 1456 filtered samples of the previous launch sit at the row's tail.  Their peak is taken
-  // here, where it is exact: with launches of a block or two (sessions, the broker) the head spans up to eight
-  // earlier launches, and "this launch and the previous one" would miss a burst that lies further back
+  // history: the newest 1456 filtered samples of the previous launch sit at the row's tail and move to its head.
+  // Their peak is taken here, where it is exact: with launches of a block or two (sessions, the broker) the head
+  // spans up to eight earlier launches, and "this launch and the previous one" would miss a burst that lies further
+  // back.  Row by row with the whole wave (coalesced; all of a row's loads in front of its stores): a lane moving its
+  // own row sample by sample took longer than the walk itself in a broker tick (64 cache lines per instruction,
+  // 1456 round trips).  With launches of fewer than eight blocks source and destination overlap: the loads of a row
+  // all lie at or above everything written before them, so the order is safe -- but only ONCE per row, which is why
+  // the spare lanes' copies of the last row are left out.
   double peak_head = 0.;
-  if (nb_mine > 0) {
-    if (first) {
-      for (int i = 0; i < kFbRing; ++i) my_row[i] = 0.;
-    } else {
-      const size_t tail = (size_t)prev_blocks * kFbFrame;
-      const double* __restrict__ prev_row = a.hp_prev ? a.hp_prev + (size_t)state_idx * row_len : my_row;
-      for (int i = 0; i < kFbRing; ++i) {
-        const double v = prev_row[tail + i];
-        my_row[i] = v;
-        peak_head = fmax(peak_head, fabs(v));
+  {
+    const int n_rows = (int)min(64u, n_signals - g0);
+    constexpr int kPer = (kFbRing + 63) / 64;
+    for (int r = 0; r < n_rows; ++r) {
+      if (__builtin_amdgcn_readlane((int)nb_mine, r) == 0) continue;
+      const size_t at = (size_t)(unsigned)__builtin_amdgcn_readlane((int)state_idx, r) * row_len;
+      double* dst = rows + at;                       // (not restrict: a short launch's source overlaps it)
+      if (__builtin_amdgcn_readlane((int)first, r)) {
+#pragma unroll
+        for (int q = 0; q < kPer; ++q)
+          if (lane + 64 * q < kFbRing) dst[lane + 64 * q] = 0.;
+      } else {
+        const double* src = (a.hp_prev ? a.hp_prev : rows) + at + (size_t)(unsigned)__builtin_amdgcn_readlane((int)prev_blocks, r) * kFbFrame;
+        double v[kPer], pm = 0.;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) v[q] = lane + 64 * q < kFbRing ? src[lane + 64 * q] : 0.;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          pm = fmax(pm, fabs(v[q]));
+          if (lane + 64 * q < kFbRing) dst[lane + 64 * q] = v[q];
+        }
+        pm = wave_max(pm);
+        if (lane == r || (r == n_rows - 1 && lane >= n_rows)) peak_head = pm;
       }
     }
   }
@@ -250,10 +267,14 @@ __global__ __launch_bounds__(64 * kHpWaves) void fb_hp_kernel(FbFrontArgs a, uns
         double y[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          const double xd = (double)xc[k];
-          y[k] = w.step(xd * a.level_factor);
+          y[k] = w.step((double)xc[k] * a.level_factor);
           peak = fmax(peak, fabs(y[k]));
-          det.step(xd, block_head && k == 4);
+        }
+        // the detector only until every lane's block has reached the threshold (a block's flag never falls back):
+        // with anything but near-silence that is its first chunk, and a quarter of the walk's instructions is gone
+        if (block_head || !__all(det.above())) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) det.step((double)xc[k], block_head && k == 4);
         }
         // 64 signals x 16 samples transposed through LDS: a store instruction writes eight 128-byte runs
 #pragma unroll
