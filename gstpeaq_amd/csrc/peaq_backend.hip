@@ -233,8 +233,7 @@ __device__ __forceinline__ void level_adapt(const BandLane<NB, SLOTS>& bl, const
       den += st[1][s];
     }
   }
-  num = wave_sum(num);
-  den = wave_sum(den);
+  wave_sum2(num, den, num, den);
   // lev = (num / den)^2 and its reciprocal, once per wave; the quotients of the per-band loop below
   // are products with reciprocals that exist anyway (1 ulp from the reference's divisions)
   const double n2 = num * num, d2 = den * den;
@@ -316,8 +315,8 @@ __device__ __forceinline__ void modulation(const BandLane<NB, SLOTS>& bl, const 
 
 // earmodel.c:891-907
 template <int NB, int SLOTS, class TAB>
-__device__ __forceinline__ double total_loudness(const BandLane<NB, SLOTS>& bl, const TAB& bt,
-                                                 const double (&exc)[SLOTS]) {
+__device__ __forceinline__ double total_loudness_part(const BandLane<NB, SLOTS>& bl, const TAB& bt,
+                                                      const double (&exc)[SLOTS]) {
   double t = 0.;
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
@@ -328,19 +327,21 @@ __device__ __forceinline__ double total_loudness(const BandLane<NB, SLOTS>& bl, 
       t += fmax(l, 0.);
     }
   }
-  return wave_sum(t) * (24. / NB);
+  return t;
 }
 
 // movs.c:709-743.  `lead`: the factor (ethres / stest)^0.23 per slot -- computed here (KEEP: and handed back) or taken
 // from a call with the same thres_fac, s0 and mod_test (USE): RmsNoiseLoudAsym's missing-components term and AvgLinDist
 // (movs.c:551-577, 679-706) share it, a logarithm and an exponential per band and block.
 enum LeadMode { LEAD_OWN, LEAD_KEEP, LEAD_USE };
+// (the lane's part of the sum over the bands: callers with several sums in a frame take them through ONE reduction,
+// wave_sum2 / wave_sum4, and finish with noise_loudness_total)
 template <int NB, int SLOTS, class TAB, LeadMode LM = LEAD_OWN>
-__device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, const TAB& bt,
-                                                 double alpha, double thres_fac, double s0, double nl_min,
-                                                 const double (&mod_ref)[SLOTS], const double (&mod_test)[SLOTS],
-                                                 const double (&e_ref)[SLOTS], const double (&e_test)[SLOTS],
-                                                 double* lead = nullptr) {
+__device__ __forceinline__ double noise_loudness_part(const BandLane<NB, SLOTS>& bl, const TAB& bt,
+                                                      double alpha, double thres_fac, double s0,
+                                                      const double (&mod_ref)[SLOTS], const double (&mod_test)[SLOTS],
+                                                      const double (&e_ref)[SLOTS], const double (&e_test)[SLOTS],
+                                                      double* lead = nullptr) {
   double nl = 0.;
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
@@ -361,7 +362,11 @@ __device__ __forceinline__ double noise_loudness(const BandLane<NB, SLOTS>& bl, 
              1.);
     }
   }
-  nl = wave_sum(nl) * (24. / NB);
+  return nl;
+}
+template <int NB>
+__device__ __forceinline__ double noise_loudness_total(double sum, double nl_min) {
+  const double nl = sum * (24. / NB);
   return nl < nl_min ? 0. : nl;
 }
 
@@ -380,9 +385,8 @@ __device__ __forceinline__ void mod_difference(const BandLane<NB, SLOTS>& bl, co
       aw += div_fast(loud_ref[s], loud_ref[s] + lev_wt * bt.noise_pow03(bl.band(s)));
     }
   }
-  d1 = wave_sum(a1);
-  d2 = wave_sum(a2);
-  wt = wave_sum(aw);
+  double unused;
+  wave_sum4(a1, a2, aw, 0., d1, d2, wt, unused);
 }
 
 // ---------------------------------------------------------------------------
@@ -513,6 +517,8 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
       excitation_from_root(v1.y, n1, m1, ut[1], lt[1]);
       nz[0] = v4.x; nz[1] = v4.y;
     }
+    double nl_part = 0.;                               // basic version: the lane's part of the noise loudness, summed with the NMR's
+    bool nl_open = false;
     // time smearing, fftearmodel.c:496-504
     double er[SLOTS], et[SLOTS];
 #pragma unroll
@@ -566,8 +572,10 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
         }
       }
       if (loud_reached == UINT_MAX) {                // wave-uniform
-        const double n_ref = total_loudness<NB, SLOTS>(bl, bt, er);
-        const double n_test = total_loudness<NB, SLOTS>(bl, bt, et);
+        double n_ref, n_test;
+        wave_sum2(total_loudness_part<NB, SLOTS>(bl, bt, er), total_loudness_part<NB, SLOTS>(bl, bt, et), n_ref, n_test);
+        n_ref *= 24. / NB;
+        n_test *= 24. / NB;
         if (lane == 0) sh.gate[chan] = (n_ref > 0.1 && n_test > 0.1);
         if (DBG && lane == 0) {
           double* __restrict__ d =
@@ -625,11 +633,9 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
         }
       }
       // ---- noise loudness (gstpeaq.c:880-886; unsigned compare with UINT_MAX sentinel)
-      if (DBG || (frame >= 24 && frame - 3 >= loud_reached)) {
-        const double nl = noise_loudness<NB, SLOTS>(bl, bt, 1.5, 0.15, 0.5, 0., mr, mt, ad_ref, ad_test);
-        if (frame >= 24 && frame - 3 >= loud_reached) route(MB_NOISELOUD, nl, 1.);
-        if (DBG && lane == 0) dmov[3] = nl;
-      }
+      // (its sum over the bands goes through the reduction of the noise-to-mask ratio below)
+      nl_open = DBG || (frame >= 24 && frame - 3 >= loud_reached);
+      if (nl_open) nl_part = noise_loudness_part<NB, SLOTS>(bl, bt, 1.5, 0.15, 0.5, mr, mt, ad_ref, ad_test);
       // ---- bandwidth (movs.c:797-807) ------------------------------------------------------
       {
         const double bw_ref = rec[kRecBwRef];
@@ -639,7 +645,8 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
         }
       }
     }
-    // ---- noise-to-mask ratio (movs.c:1002-1022) ---------------------------------------
+    // ---- noise-to-mask ratio (movs.c:1002-1022), detection probability's binaural part (movs.c:1263-1275): the
+    // lanes' parts first, then ONE reduction for the three sums of this place (with the noise loudness's from above) ----
     {
       double nsum = 0., nmax = 0.;
 #pragma unroll
@@ -650,8 +657,38 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
           if (r > nmax) nmax = r;
         }
       }
-      nsum = wave_sum(nsum) / NB;
-      nmax = wave_max(nmax);
+      double pprod = 1., qsum = 0.;
+      if (!ADV && chan == 0) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+          if (bl.valid(s)) {
+            const int b = bl.band(s);
+            double p = 0., q = sh.qc[0][b];
+            if (sh.pc[0][b] > p) p = sh.pc[0][b];
+            if (channels == 2) {
+              if (sh.pc[1][b] > p) p = sh.pc[1][b];
+              if (sh.qc[1][b] > q) q = sh.qc[1][b];
+            }
+            pprod *= 1. - p;
+            qsum += q;
+          }
+        }
+      }
+      double nl_sum, none;
+      if (!ADV)
+        wave_sum4(nsum, nl_part, qsum, 0., nsum, nl_sum, qsum, none);
+      else
+        nsum = wave_sum(nsum);
+      nsum /= NB;
+      // RelDistFrames asks whether ANY band's ratio is above 1.5 dB: a vote, not a maximum (the debug build reports the value)
+      const bool disturbed = __any(nmax > 1.41253754462275);
+      if (DBG) nmax = wave_max(nmax);
+      if (!ADV && nl_open) {
+        const double nl = noise_loudness_total<NB>(nl_sum, 0.);
+        if (frame >= 24 && frame - 3 >= loud_reached) route(MB_NOISELOUD, nl, 1.);
+        if (DBG && lane == 0)
+          a.debug[((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels + chan) * kDbgDoubles + kDbgMov + 3] = nl;
+      }
       if (DBG && lane == 0) {
         double* __restrict__ d =
             a.debug + ((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels + chan) * kDbgDoubles + kDbgMov;
@@ -660,45 +697,28 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
       }
       if (!ADV) {
         route(MB_NMR, nsum, 1.);                                    // MODE_AVG_LOG
-        route(MB_RELDIST, nmax > 1.41253754462275 ? 1. : 0., 1.);
+        route(MB_RELDIST, disturbed ? 1. : 0., 1.);
       } else {
         const double seg = (10. * kInvLn10) * log_pos(nsum);        // 10 log10, MODE_AVG; nsum > 0 (floored bands)
         route(MA_SEGNMR, seg, 1.);
         if (DBG && lane == 0)
           a.debug[((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels + chan) * kDbgDoubles + kDbgMov + 3] = seg;
       }
+      if (!ADV && chan == 0) {
+        const double p_bin = 1. - wave_prod(pprod);
+        if (DBG && lane == 0) {
+          double* __restrict__ d =
+              a.debug + ((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels) * kDbgDoubles + kDbgMov;
+          d[6] = p_bin;
+          d[7] = qsum;
+        }
+        if (p_bin > 0.5) route(MB_ADB, qsum, 1.);
+        route(MB_MFPD, p_bin, 1.);
+      }
     }
     // ---- error harmonic structure (movs.c:1374-1381,1442) ------------------------------
     if (ehs_valid) {
       route(ADV ? MA_EHS : MB_EHS, 1000. * rec[kRecEhs], 1.);
-    }
-    // ---- detection probability, binaural part (movs.c:1263-1275) --------------------------
-    if (!ADV && chan == 0) {
-      double pprod = 1., qsum = 0.;
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s) {
-        if (bl.valid(s)) {
-          const int b = bl.band(s);
-          double p = 0., q = sh.qc[0][b];
-          if (sh.pc[0][b] > p) p = sh.pc[0][b];
-          if (channels == 2) {
-            if (sh.pc[1][b] > p) p = sh.pc[1][b];
-            if (sh.qc[1][b] > q) q = sh.qc[1][b];
-          }
-          pprod *= 1. - p;
-          qsum += q;
-        }
-      }
-      const double p_bin = 1. - wave_prod(pprod);
-      qsum = wave_sum(qsum);
-      if (DBG && lane == 0) {
-        double* __restrict__ d =
-            a.debug + ((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels) * kDbgDoubles + kDbgMov;
-        d[6] = p_bin;
-        d[7] = qsum;
-      }
-      if (p_bin > 0.5) route(MB_ADB, qsum, 1.);
-      route(MB_MFPD, p_bin, 1.);
     }
     // ---- totalsnr (gstpeaq.c:913-918) --------------------------------------------------------
     if (chan == 0 && lane == 0) {
@@ -863,8 +883,10 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
     double* __restrict__ dbg =
         DBG ? a.debug + ((size_t)(pair * a.blocks_per_launch + (blk - b_begin)) * channels + chan) * kDbgFbDoubles : nullptr;
     if (loud_reached == UINT_MAX) {                  // workgroup-uniform
-      const double n_ref = total_loudness<NB, SLOTS>(bl, bt, er);
-      const double n_test = total_loudness<NB, SLOTS>(bl, bt, et);
+      double n_ref, n_test;
+      wave_sum2(total_loudness_part<NB, SLOTS>(bl, bt, er), total_loudness_part<NB, SLOTS>(bl, bt, et), n_ref, n_test);
+      n_ref *= 24. / NB;
+      n_test *= 24. / NB;
       if (lane == 0) sh.gate[chan] = (n_ref > 0.1 && n_test > 0.1);
       if (DBG && lane == 0) {
         dbg[5] = n_ref;
@@ -895,13 +917,18 @@ __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
       // movs.c:551-577; SWAP_MOD_PATTS_FOR_NOISE_LOUDNESS_MOVS (shipped: 1) exchanges the modulation
       // patterns of the missing-components term ...
       const bool swap = a.cfg.swap_mod_patts != 0;   // workgroup-uniform
-      const double nl = noise_loudness<NB, SLOTS>(bl, bt, 2.5, 0.3, 1., 0.1, mr, mt, ad_ref, ad_test);
+      const double nl_p = noise_loudness_part<NB, SLOTS>(bl, bt, 2.5, 0.3, 1., mr, mt, ad_ref, ad_test);
       double lead[SLOTS] = {};                       // (ethres / stest)^0.23: the same stest in both calls below
-      const double mc = noise_loudness<NB, SLOTS, GlobalTabs, LEAD_KEEP>(bl, bt, 1.5, 0.15, 1., 0., swap ? mt : mr,
-                                                                         swap ? mr : mt, ad_test, ad_ref, lead);
+      const double mc_p = noise_loudness_part<NB, SLOTS, GlobalTabs, LEAD_KEEP>(bl, bt, 1.5, 0.15, 1., swap ? mt : mr,
+                                                                                swap ? mr : mt, ad_test, ad_ref, lead);
       // ... and (movs.c:679-706) takes the reference modulation twice; unadapted FB excitation
-      const double ld = noise_loudness<NB, SLOTS, GlobalTabs, LEAD_USE>(bl, bt, 1.5, 0.15, 1., 0., mr, swap ? mr : mt, ad_ref,
-                                                                        er, lead);
+      const double ld_p = noise_loudness_part<NB, SLOTS, GlobalTabs, LEAD_USE>(bl, bt, 1.5, 0.15, 1., mr, swap ? mr : mt,
+                                                                               ad_ref, er, lead);
+      double nl, mc, ld, none;                       // the three sums over the bands in one reduction
+      wave_sum4(nl_p, mc_p, ld_p, 0., nl, mc, ld, none);
+      nl = noise_loudness_total<NB>(nl, 0.1);
+      mc = noise_loudness_total<NB>(mc, 0.);
+      ld = noise_loudness_total<NB>(ld, 0.);
       const bool open = blk >= 125 && blk - 13 >= loud_reached;
       if (open && lane == MA_NLASYM) {
         v0 = nl;

@@ -493,15 +493,13 @@ void frontend_kernel(FrontendArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   FE_MARK(14);                                       // sample loads + window
-  hop = wave_sum(hop);
+  wave_sum2(hop, energy, hop, energy);
   if (lane == 0) rec[sig ? kRecNoiseE : kRecSigE] = hop;
-  energy = wave_sum(energy);
   const int energy_flag = energy >= 8000. / (32768. * 32768.);
 
   int above = 0;
   if (sig == 0) {
-    const float amax_w = (float)wave_max((double)amax);
-    if ((double)amax_w >= 200. / 32768 + 1e-6) {
+    if (__any((double)amax >= 200. / 32768 + 1e-6)) {   // (a vote: nobody needs the maximum itself)
       above = 1;
     } else {
       // quiet frame: stage |x| (8 KiB, start of the still unused FFT buffer) and decide exactly
@@ -699,7 +697,15 @@ void frontend_kernel(FrontendArgs a) {
         const double g_iu = div_fast(1. - exp_fast((double)(NB - b) * ln_a), 1. - a_uce);
         ae[s] = t2;
         ene[s] = exp_fast(0.4 * (ln_pp - FE_LOG(c_gil[s] + g_iu - 1., ltab)));
-        far[s] = ene[s] * exp_fast((0.4 * (2 * kLanes - s)) * ln_a);
+        {                                              // a^(0.4 (2 kLanes - s)) = t2^(2 kLanes - s), by squaring: the exponent
+          double pw = 1., sq = t2;                   // is a compile-time constant (ten multiplications for an exponential)
+#pragma unroll
+          for (int e = 2 * kLanes - s; e; e >>= 1) {
+            if (e & 1) pw *= sq;
+            if (e >> 1) sq *= sq;
+          }
+          far[s] = ene[s] * pw;
+        }
         back2[s] = div_fast(1., t2 * t2);
       } else {
         ae[s] = 0.;

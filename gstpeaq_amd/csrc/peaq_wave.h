@@ -294,6 +294,47 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ __forceinline__ double wave_max(double v) {
   return wave_reduce_d(v, [](double x, double y) { return fmax(x, y); });
 }
+// Several sums for the price of one.  v_permlane32_swap hands the upper half of its first operand to the second and
+// takes the second's lower half: with two DIFFERENT values as operands the sum of the two results is, in lanes 0 .. 31,
+// the first value's lane + (lane + 32), and in lanes 32 .. 63 the second's -- one level of both reductions in the
+// three instructions per double that one level of one reduction takes.  v_permlane16_swap does the same for the rows,
+// so four values share the rest of the way (rows 0 .. 3 end as the sums of a, c, b, d).  The totals are read through
+// the scalar unit: uniform, and bit-identical in every lane like wave_sum's.
+__device__ __forceinline__ double fuse_halves_sum(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double fuse_rows_sum(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double row_sum_d(double v) {      // every lane: the sum over its row of 16
+  v += dpp_d<kDppXor1>(v);
+  v += dpp_d<kDppXor2>(v);
+  v += dpp_d<kDppHalfMirror>(v);
+  v += dpp_d<kDppMirror>(v);
+  return v;
+}
+__device__ __forceinline__ double lane_value_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ void wave_sum2(double a, double b, double& sa, double& sb) {
+  double v = fuse_halves_sum(a, b), p, q;            // lanes 0 .. 31: a, lanes 32 .. 63: b
+  swap_halves_d<true>(v, p, q);
+  v = row_sum_d(p + q);
+  sa = lane_value_d(v, 0);
+  sb = lane_value_d(v, 32);
+}
+__device__ __forceinline__ void wave_sum4(double a, double b, double c, double d, double& sa, double& sb, double& sc,
+                                          double& sd) {
+  const double v = row_sum_d(fuse_rows_sum(fuse_halves_sum(a, b), fuse_halves_sum(c, d)));
+  sa = lane_value_d(v, 0);
+  sc = lane_value_d(v, 16);
+  sb = lane_value_d(v, 32);
+  sd = lane_value_d(v, 48);
+}
 __device__ __forceinline__ double wave_prod(double v) {
   return wave_reduce_d(v, [](double x, double y) { return x * y; });
 }
