@@ -178,12 +178,15 @@ struct GlobalTabs {
   __device__ __forceinline__ double deriv_factor() const { return p->deriv_factor; }
   // transcendentals of the MOV layer: the logarithm from the table in LDS (see LdsTabs)
   const double* ltab;
+  const double* etab;               // ... and the exponential from its own (exp_tab, peaq_wave.h)
 #if defined(PEAQ_LEDGER_FP32_BACKEND) || defined(PEAQ_NO_LOGTAB_BE)
   __device__ __forceinline__ double log(double x) const { return be_log(x); }
+  __device__ __forceinline__ double exp(double x) const { return be_exp(x); }
   __device__ __forceinline__ double pow(double x, double y) const { return be_pow(x, y); }
 #else
   __device__ __forceinline__ double log(double x) const { return log_tab(x, ltab); }
-  __device__ __forceinline__ double pow(double x, double y) const { return be_exp(y * log_tab(x, ltab)); }
+  __device__ __forceinline__ double exp(double x) const { return exp_tab(x, etab); }
+  __device__ __forceinline__ double pow(double x, double y) const { return exp_tab(y * log_tab(x, ltab), etab); }
 #endif
 };
 enum { T_ADAPT, T_EAR, T_THR, T_LOUDF, T_EXCTHR, T_INOISE, T_NPOW03, T_MASK, T_ISN, T_ISN03, T_LNINOISE, T_RCNT, T_COUNT };
@@ -206,11 +209,15 @@ struct LdsTabs {
   // transcendentals of the MOV layer: the logarithm from the 129-entry table in LDS (log_tab, peaq_wave.h) --
   // ten logarithms per band and frame are a tenth of this kernel's vector instructions otherwise
   const double* ltab;               // [kLogTabEntries][2] in LDS
+  // (the exponential stays the polynomial here: this kernel runs beside the front end, whose LDS array is the busier
+  // unit -- with exp_tab the basic step measured 0 ... - 1 %, the filter-bank back end above + 0.8 % on its pass)
 #if defined(PEAQ_LEDGER_FP32_BACKEND) || defined(PEAQ_NO_LOGTAB_BE)
   __device__ __forceinline__ double log(double x) const { return be_log(x); }
+  __device__ __forceinline__ double exp(double x) const { return be_exp(x); }
   __device__ __forceinline__ double pow(double x, double y) const { return be_pow(x, y); }
 #else
   __device__ __forceinline__ double log(double x) const { return log_tab(x, ltab); }
+  __device__ __forceinline__ double exp(double x) const { return be_exp(x); }
   __device__ __forceinline__ double pow(double x, double y) const { return be_exp(y * log_tab(x, ltab)); }
 #endif
 };
@@ -349,13 +356,13 @@ __device__ __forceinline__ double noise_loudness_part(const BandLane<NB, SLOTS>&
       const double sref = thres_fac * mod_ref[s] + s0;
       const double stest = thres_fac * mod_test[s] + s0;
       const double ethres = bt.internal_noise(bl.band(s));
-      const double beta = be_exp(div_fast(-alpha * (e_test[s] - e_ref[s]), e_ref[s]));
+      const double beta = bt.exp(div_fast(-alpha * (e_test[s] - e_ref[s]), e_ref[s]));
       // (ethres / stest)^0.23 from the logarithms: ln ethres is a table entry
       double ld;
       if (LM == LEAD_USE)
         ld = lead[s];
       else
-        ld = be_exp(0.23 * (bt.ln_internal_noise(bl.band(s)) - bt.log(stest)));
+        ld = bt.exp(0.23 * (bt.ln_internal_noise(bl.band(s)) - bt.log(stest)));
       if (LM == LEAD_KEEP) lead[s] = ld;
       nl += ld *
             (bt.pow(1. + div_fast(fmax(stest * e_test[s] - sref * e_ref[s], 0.), ethres + sref * e_ref[s] * beta), 0.23) -
@@ -594,14 +601,14 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
           const double l = 0.3 * fmax(er_db, et_db) + 0.7 * et_db;
           const double l2 = l * l;
           // (6.39468 / l)^1.71332 = exp(1.71332 (ln 6.39468 - ln l)); one reciprocal of s for both quotients
-          const double sd = l > 0. ? 5.95072 * be_exp(1.71332 * (1.8554663946857675 - bt.log(l))) + 9.01033e-11 * l2 * l2 +
+          const double sd = l > 0. ? 5.95072 * bt.exp(1.71332 * (1.8554663946857675 - bt.log(l))) + 9.01033e-11 * l2 * l2 +
                                          5.05622e-6 * l2 * l - 0.00102438 * l * l + 0.0550197 * l - 0.198719
                                    : 1e30;
           const double inv_sd = div_fast(1., sd);
           const double e = er_db - et_db;
           const double x = e * inv_sd, x2 = x * x;
           const double xb = er_db > et_db ? x2 * x2 : x2 * x2 * x2;   // (e/s)^b, b = 4 or 6
-          pc = 1. - be_exp(-kLn2 * xb);                             // 1 - 0.5^((e/s)^b)
+          pc = 1. - bt.exp(-kLn2 * xb);                             // 1 - 0.5^((e/s)^b)
           qc = fabs(a.cfg.floor_steps ? floor(e) : trunc(e)) * inv_sd;        // movs.c:1256-1260
         }
         sh.pc[chan][bl.band(s)] = pc;
@@ -797,14 +804,16 @@ template <bool DBG>
 __global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
   __shared__ FbBackendShared sh;
   __shared__ __attribute__((aligned(16))) double sh_ltab[2 * kLogTabEntries + 2];
+  __shared__ double sh_etab[kExpTabEntries];
   constexpr int NB = kFbBands, SLOTS = 1;
   const int lane = threadIdx.x & 63;
   const int chan = threadIdx.x >> 6;
   const int channels = a.channels;
   const unsigned pair = blockIdx.x;
   for (int i = threadIdx.x; i < 2 * kLogTabEntries; i += blockDim.x) sh_ltab[i] = a.common->log_tab[i >> 1][i & 1];
+  if (threadIdx.x < kExpTabEntries) sh_etab[threadIdx.x] = a.common->exp_tab[threadIdx.x];
   __syncthreads();
-  const GlobalTabs bt{a.bands, sh_ltab};
+  const GlobalTabs bt{a.bands, sh_ltab, sh_etab};
   const BandLane<NB, SLOTS> bl{lane};
   unsigned b_begin, b_end, slot = pair;
   if (a.windows) {                                   // broker launch: this session's own window and state

@@ -107,8 +107,12 @@ struct CommonTables {
   // {2, 0} and {1, 0}: there r = x - 1 exactly and the power of two counts 0, so ln 1 = 0 and the
   // relative accuracy holds however close to 1 the argument is.
   double log_tab[130][2];
+  // Exponential by table (exp_tab, peaq_wave.h): e^x = 2^k 2^(j/64) e^r with x = (64 k + j) ln 2 / 64 + r,
+  // |r| <= ln 2 / 128: [j] = 2^(j/64), rounded to nearest
+  double exp_tab[64];
 };
 constexpr int kLogTabEntries = 129;
+constexpr int kExpTabEntries = 64;
 constexpr int kLogTabFold = 54;     // first bin whose centre lies above sqrt 2
 
 struct BandTables {             // earmodel.c:279-323 + fftearmodel.c:693-788

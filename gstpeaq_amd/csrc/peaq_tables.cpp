@@ -421,6 +421,7 @@ void build_common_tables(CommonTables& c) {
     c.ehs_window_centred[i] = 0.81649658092773 * (1.0 + std::cos(2 * kPi * i / 511.0)) / 256.0;
   }
   fill_log_tab(c.log_tab);
+  for (int j = 0; j < kExpTabEntries; ++j) c.exp_tab[j] = (double)exp2l(j / 64.0L);
 }
 
 void fill_log_tab(double (*tab)[2]) {                 // log_tab (peaq_device.h), 130 entries

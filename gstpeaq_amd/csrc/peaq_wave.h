@@ -465,6 +465,23 @@ template <bool SK = PEAQ_SK_DEFAULT> __device__ __forceinline__ double log_nonne
 
 // e^x for any finite x or -inf (underflows to 0, overflows to inf through ldexp).
 // x = n ln 2 + r, |r| <= 0.3466; e^r as its Taylor polynomial of degree 12 (truncation 1.7e-16).
+// e^x like exp_fast below, from the 64-entry table CommonTables::exp_tab (2^(j/64)) the caller holds in LDS: the
+// argument is reduced to |r| <= ln 2 / 128, where e^r - 1 needs five terms instead of twelve (the next one is 3.5e-17
+// relative) -- and every term of such a chain costs its multiply-add AND a move of its constant into the two-address
+// accumulator.  64 ln 2 / 64 is split like ln 2 itself: the high part's product with n (17 bits) is exact.
+__device__ __forceinline__ double exp_tab(double x, const double* __restrict__ tab) {
+  x = fmin(fmax(x, -1000.), 1000.);
+  const double n = __builtin_rint(x * 9.23324826168936580e+01);           // 64 / ln 2
+  double r = fma(-n, 6.93147180369123816490e-01 / 64, x);
+  r = fma(-n, 1.90821492927058770002e-10 / 64, r);
+  const int ni = (int)n;
+  const double t = tab[ni & 63];
+  double p = fma(r, 1. / 120., 1. / 24.);
+  p = fma(p, r, 1. / 6.);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.);
+  return __builtin_amdgcn_ldexp(fma(t, p * r, t), ni >> 6);
+}
 template <bool SK = PEAQ_SK_DEFAULT> __device__ __forceinline__ double exp_fast(double x) {
   x = fmin(fmax(x, -1000.), 1000.);
   const double n = __builtin_rint(x * PEAQ_KC(1.44269504088896338700e+00));
