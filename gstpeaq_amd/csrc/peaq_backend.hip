@@ -800,8 +800,11 @@ struct FbBackendShared {
 
 // DBG = true (peaq_debug_backend_advanced): the block's MOV values are computed for every block and written to
 // a.debug; the arithmetic is the same instantiation otherwise.
+// (held to 128 registers -- 44 B of them spilled around the block loop, none inside: beside the FP64 bank this kernel
+// runs in the place of ONE of a CU's two bank workgroups, 272 registers per SIMD lane, and two of its waves fit there
+// instead of one: + 0.5 % on the advanced pass)
 template <bool DBG>
-__global__ __launch_bounds__(128) void fb_backend_kernel(FbBackendArgs a) {
+__global__ __launch_bounds__(128, 4) void fb_backend_kernel(FbBackendArgs a) {
   __shared__ FbBackendShared sh;
   __shared__ __attribute__((aligned(16))) double sh_ltab[2 * kLogTabEntries + 2];
   __shared__ double sh_etab[kExpTabEntries];
