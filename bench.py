@@ -154,8 +154,47 @@ def cpu_all_cores(n_samples, channels, seed0, advanced, budget_s=8.0):
                        + (f" ({late} processes started late)" if late else ""))
 
 
+def cpu_records(n_samples, channels, seed0, advanced, pairs, procs=None, timeout=3000):
+    """The reference's per-pair results (MOVs, DI, ODG) for the seeded pairs seed0 .. seed0 + pairs - 1, one process
+    per usable core, each on its own contiguous block of seeds (`ref_harness time`, repeats = 0: every pair generated,
+    then run through the element once).  -> dict(odg, di, movs (flat, 11 per pair), pairs, seconds, cores, kind)."""
+    tool, kind, what = _cpu_tool()
+    cores, _ = _cpu_limit()
+    procs = max(1, min(procs or cores, pairs))
+    per, extra = divmod(pairs, procs)
+    blocks, s = [], seed0
+    for i in range(procs):
+        n = per + (1 if i < extra else 0)
+        blocks.append((s, n))
+        s += n
+    t0 = time.time()
+    running = [(subprocess.Popen([tool, "time", str(int(advanced)), str(channels), str(b0), str(n), str(n_samples)],
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True), n) for b0, n in blocks if n]
+    out = dict(odg=[], di=[], movs=[])
+    for p, n in running:
+        o, e = p.communicate(timeout=max(1.0, t0 + timeout - time.time()))
+        if p.returncode != 0:
+            for q, _ in running:
+                q.kill()
+            raise RuntimeError(f"{tool} failed: {e[-300:]}")
+        d = json.loads(o.strip().splitlines()[-1].replace('"nan"', "NaN").replace('"inf"', "Infinity").replace('"-inf"', "-Infinity"))
+        if len(d["odg"]) != n:
+            raise RuntimeError(f"{tool}: {len(d['odg'])} records for {n} pairs")
+        for k in out:
+            out[k] += d[k]
+    out.update(pairs=pairs, seconds=time.time() - t0, cores=len(running), kind=kind, what=what)
+    return out
+
+
+# MOVs behind a discrete gate (a threshold decides whether a frame counts at all): the ones where a last-bit
+# difference upstream could show as a step instead of as a last-bit difference
+GATED_MOVS = ("BandwidthRefB", "BandwidthTestB", "RelDistFramesB", "ADBB", "MFPDB")
+
+
 def result_deltas(gpu_rows, cpu, advanced):
-    """max |delta| of GPU vs CPU results over the pairs of the single-core leg (same seeds, same order)"""
+    """GPU vs the reference's results over the pairs `cpu` holds (same seeds, same order): maxima and 99th percentiles
+    of |delta ODG|, |delta DI|, the largest relative difference per MOV, NaN mismatches, and for the discretely gated
+    MOVs the number of pairs on which they differ AT ALL beyond rounding (relative 1e-9)."""
     import numpy as np
     from gstpeaq_amd.capi import MOV_NAMES_ADVANCED, MOV_NAMES_BASIC
     n = len(cpu["odg"])
@@ -165,14 +204,21 @@ def result_deltas(gpu_rows, cpu, advanced):
     names = MOV_NAMES_ADVANCED if advanced else MOV_NAMES_BASIC
     nan_mismatch = int((np.isnan(g[:, 12]) != np.isnan(odg_c)).sum())
     ok = ~np.isnan(odg_c) & ~np.isnan(g[:, 12])
-    mov_rel = {}
+    mov_rel, gated = {}, {}
     for i, name in enumerate(names):
         a, b = g[ok, i], movs_c[ok, i]
         den = np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-12)
-        mov_rel[name] = float(np.max(np.abs(a - b) / den)) if a.size else None
-    return dict(odg_max_abs_delta=float(np.max(np.abs(g[ok, 12] - odg_c[ok]))) if ok.any() else None,
-                di_max_abs_delta=float(np.max(np.abs(g[ok, 11] - di_c[ok]))) if ok.any() else None,
-                mov_max_rel_delta=mov_rel, delta_pairs=int(n), delta_nan_mismatches=nan_mismatch)
+        rel = np.abs(a - b) / den
+        mov_rel[name] = float(np.max(rel)) if a.size else None
+        if name in GATED_MOVS:
+            gated[name] = int((rel > 1e-9).sum())
+    d_odg, d_di = np.abs(g[ok, 12] - odg_c[ok]), np.abs(g[ok, 11] - di_c[ok])
+    return dict(odg_max_abs_delta=float(np.max(d_odg)) if ok.any() else None,
+                odg_p99_abs_delta=float(np.percentile(d_odg, 99)) if ok.any() else None,
+                di_max_abs_delta=float(np.max(d_di)) if ok.any() else None,
+                di_p99_abs_delta=float(np.percentile(d_di, 99)) if ok.any() else None,
+                mov_max_rel_delta=mov_rel, gated_movs_pairs_differing=gated,
+                delta_pairs=int(n), delta_nan_mismatches=nan_mismatch)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -300,6 +346,8 @@ def main():
     ap.add_argument("--reduced-precision", action="store_true",
                     help="with --advanced: time the opt-in split-FP16 FIR (PEAQ_FIR_F16X3) instead of the default all-FP64 engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--delta-pairs", type=int, default=256,
+                    help="pairs whose results are compared with the reference's (both versions; all host cores)")
     ap.add_argument("--no-scaling-reference", action="store_true",
                     help="skip the waves-mode pass that makes an N = 1 line comparable with N > 1 lines")
     args = ap.parse_args()
@@ -665,10 +713,17 @@ def main():
 
     # ---- CPU legs: rank 0.  At N = 1 one core, all usable cores, and the advanced version's leg; at N > 1 the
     # one-core leg only (the other ranks wait at the final barrier meanwhile; nothing is being timed any more).
+    # The comparison with the reference's results (`odg_max_abs_delta` ...) runs on the FIRST `--delta-pairs` pairs of
+    # the job (256: SURVEY.md 8(d)) in both versions, through one reference process per usable host core; the one-core
+    # leg only times.
     if rank == 0 and not args.no_cpu_baseline:
         try:
-            base, cpu = cpu_single(n_samples, args.channels, seed_base + lo, main_adv, 12.0)
+            base, cpu = cpu_single(n_samples, args.channels, seed_base + lo, main_adv, 8.0)
             line["cpu_baseline"] = base
+            n_delta = min(args.delta_pairs, len(rows_main)) if world == 1 else len(cpu["odg"])
+            if n_delta > len(cpu["odg"]):
+                cpu = cpu_records(n_samples, args.channels, seed_base + lo, main_adv, n_delta)
+                line["delta_how"] = f"{cpu['pairs']} pairs through {cpu['what']} on {cpu['cores']} processes, {cpu['seconds']:.1f} s"
             line.update(result_deltas(rows_main, cpu, main_adv))
             line["delta_vs"] = base["kind"]
             if world == 1:
@@ -676,8 +731,13 @@ def main():
                 if allc:
                     line["cpu_baseline"]["all_cores"] = allc
                 if adv is not None and rows_adv is not None:
-                    abase, acpu = cpu_single(n_samples, args.channels, seed_base + lo, True, 16.0)   # >= 32 pairs
+                    abase, acpu = cpu_single(n_samples, args.channels, seed_base + lo, True, 6.0)
                     adv["cpu_baseline"] = abase
+                    n_delta = min(args.delta_pairs, len(rows_adv))
+                    if n_delta > len(acpu["odg"]):
+                        acpu = cpu_records(n_samples, args.channels, seed_base + lo, True, n_delta)
+                        adv["delta_how"] = (f"{acpu['pairs']} pairs through {acpu['what']} on {acpu['cores']} processes, "
+                                            f"{acpu['seconds']:.1f} s")
                     adv.update(result_deltas(rows_adv, acpu, True))
                     adv["delta_vs"] = abase["kind"]
         except Exception as e:                               # the bench line must survive a broken baseline leg

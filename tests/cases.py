@@ -25,7 +25,30 @@ def make_inputs(case):
             test = test * np.float32(2.0 ** -sh)
         ref = ref[: case["n"] - case.get("ref_trim", 0)]
         test = test[: case["n"] - case.get("test_trim", 0)]
-        return np.ascontiguousarray(ref), np.ascontiguousarray(test)
+        ref, test = np.ascontiguousarray(ref), np.ascontiguousarray(test)
+        # input classes beyond "a clean pair" (all float32 arithmetic, in this order)
+        if case.get("chan_gain"):                      # channels at different levels (binaural maxima, movs.c:1224-1276)
+            g = np.asarray(case["chan_gain"], dtype=np.float32)[None, :]
+            ref, test = ref * g, test * g
+        if case.get("gain"):                           # drive into full scale ...
+            ref, test = ref * np.float32(case["gain"]), test * np.float32(case["gain"])
+        if case.get("clip"):                           # ... and clip hard: "both" or "test"
+            if case["clip"] == "both":
+                ref = np.clip(ref, np.float32(-1), np.float32(1))
+            test = np.clip(test, np.float32(-1), np.float32(1))
+        if case.get("dc_ref"):
+            ref = ref + np.float32(case["dc_ref"])
+        if case.get("dc_test"):
+            test = test + np.float32(case["dc_test"])
+        if case.get("invert_test"):
+            test = -test
+        for start, length in case.get("gaps", ()):     # digital silence in mid-stream (NORMAL -> TENTATIVE -> NORMAL in the
+            who = case.get("gap_who", "both")          # accumulators, movaccum.c:317-352; the detector looks at ref only)
+            if who in ("both", "ref"):
+                ref[start:start + length] = 0
+            if who in ("both", "test"):
+                test[start:start + length] = 0
+        return np.ascontiguousarray(ref, dtype=np.float32), np.ascontiguousarray(test, dtype=np.float32)
     if kind == "ats":
         ref = synth_np.audiotestsrc(case["wave_ref"], case["n"])
         test = synth_np.audiotestsrc(case["wave_test"], case["n"])
@@ -63,9 +86,30 @@ def e2e_cases():
         cases.append(dict(name="synth_quiet_60dB", kind="synth", seed=29, channels=1, n=96000, atten_shift=10))
         cases.append(dict(name="synth_quiet_84dB", kind="synth", seed=30, channels=2, n=96000, atten_shift=14))
         cases.append(dict(name="silence", kind="silence", channels=2, n=48000))
+        cases += input_class_cases()
         for c in cases:
             c.setdefault("advanced", adv)
     return cases
+
+
+def input_class_cases():
+    """Input classes a clean seeded pair does not reach (round 6): digital silence in MID-stream -- one gap, three
+    gaps, whole frames and parts of frames, in both signals / the reference only / the test only --, hard clipping at
+    full scale, DC offsets, a polarity-inverted test signal, channels 40 dB apart."""
+    one, three = [(40000, 20000)], [(20000, 6000), (50000, 12000), (90000, 3000)]
+    return [
+        dict(name="gap1_stereo", kind="synth", seed=40, channels=2, n=120000, gaps=one),
+        dict(name="gap3_stereo", kind="synth", seed=41, channels=2, n=120000, gaps=three),
+        dict(name="gap1_mono", kind="synth", seed=42, channels=1, n=120000, gaps=one),
+        dict(name="gap3_mono", kind="synth", seed=43, channels=1, n=120000, gaps=three),
+        dict(name="gap3_ref_only_stereo", kind="synth", seed=44, channels=2, n=120000, gaps=three, gap_who="ref"),
+        dict(name="gap1_test_only_mono", kind="synth", seed=45, channels=1, n=120000, gaps=one, gap_who="test"),
+        dict(name="clip_both_stereo", kind="synth", seed=46, channels=2, n=96000, gain=6.0, clip="both"),
+        dict(name="clip_test_mono", kind="synth", seed=47, channels=1, n=96000, gain=3.0, clip="test"),
+        dict(name="dc_offsets_stereo", kind="synth", seed=48, channels=2, n=96000, dc_ref=0.05, dc_test=-0.125),
+        dict(name="inverted_test_stereo", kind="synth", seed=49, channels=2, n=96000, invert_test=1),
+        dict(name="channels_40dB_apart", kind="synth", seed=50, channels=2, n=96000, chan_gain=[1.0, 0.01]),
+    ]
 
 
 def level_cases():

@@ -136,7 +136,8 @@ def test_backend_patterns_match_oracle_per_frame(gpu, case):
     dict(kind="synth", seed=9, channels=2, n=40000, atten_shift=9),   # around the detector thresholds
     dict(kind="synth", seed=26, channels=2, n=40000, identical=1),
     dict(kind="ats", wave_ref="saw", wave_test="triangle", n=65536, channels=1),
-], ids=["mono", "stereo-ragged", "lead-silence", "quiet", "identical", "saw-triangle"])
+    dict(kind="synth", seed=41, channels=2, n=60000, gaps=[(20000, 9000), (40000, 3000)]),   # silence in mid-stream
+], ids=["mono", "stereo-ragged", "lead-silence", "quiet", "identical", "saw-triangle", "mid-gaps"])
 def test_mov_values_match_oracle_per_frame(gpu, case):
     """The MOV layer frame by frame, before the accumulators: modulation differences and their weight
     (movs.c:205-254), noise loudness (:354-371), mean and maximum of the band noise-to-mask ratios (:971-1023),
@@ -175,11 +176,12 @@ ADV_STAGE_CASES = [
     dict(kind="synth", seed=9, channels=2, n=40000, atten_shift=9),   # around the detector thresholds
     dict(kind="synth", seed=26, channels=2, n=40000, identical=1),
     dict(kind="ats", wave_ref="saw", wave_test="triangle", n=65536, channels=1),
+    dict(kind="synth", seed=41, channels=2, n=60000, gaps=[(20000, 9000), (40000, 3000)]),   # silence in mid-stream
 ]
 
 
 @pytest.mark.parametrize("case", ADV_STAGE_CASES,
-                         ids=["mono", "stereo-ragged", "lead-silence", "quiet", "identical", "saw-triangle"])
+                         ids=["mono", "stereo-ragged", "lead-silence", "quiet", "identical", "saw-triangle", "mid-gaps"])
 def test_advanced_mov_values_match_oracle_per_block_and_frame(gpu, case, fir_mode):
     """The advanced version's MOV layer block by block and frame by frame, before the accumulators: RmsModDiffA and
     its weight (movs.c:205-254 with the RMS normalisation of :243-244), the noise loudness and the missing-components

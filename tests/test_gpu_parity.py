@@ -60,7 +60,8 @@ def oracle_records(bands, ref, test, n_frames):
     dict(kind="synth", seed=9, channels=2, n=20000, atten_shift=9),   # around the detector thresholds
     dict(kind="synth", seed=26, channels=2, n=12000, identical=1),
     dict(kind="ats", wave_ref="saw", wave_test="triangle", n=16384, channels=1),
-], ids=["mono", "stereo-ragged", "lead-silence", "quiet", "identical", "saw-triangle"])
+    dict(kind="synth", seed=41, channels=2, n=30000, gaps=[(8000, 9000)]),   # digital silence in mid-stream
+], ids=["mono", "stereo-ragged", "lead-silence", "quiet", "identical", "saw-triangle", "mid-gap"])
 def test_frontend_records_match_oracle(gpu, bands, case):
     """stage-level: every field of the per-frame record (unsmeared excitation,
     loudness^0.3, noise in bands, bandwidths, EHS, flags, energies)"""

@@ -78,7 +78,8 @@ def e2e():
             test.astype("<f4").tofile(tp)
             r = run_harness("pair", case["advanced"], case["channels"], rp, tp)
             if case["kind"] == "synth" and not any(case.get(k) for k in
-                                                   ("identical", "swap", "atten_shift", "ref_trim", "test_trim")):
+                                                   ("identical", "swap", "atten_shift", "ref_trim", "test_trim", "chan_gain", "gain", "clip",
+                                                    "dc_ref", "dc_test", "invert_test", "gaps")):
                 # cross-check the numpy generator against the C header through the harness
                 r2 = run_harness("synth", case["advanced"], case["channels"], case["seed"], case["n"])
                 assert r2["movs"] == r["movs"], case["name"]
