@@ -254,6 +254,56 @@ def device_power_info(index):
     return info
 
 
+class DeviceSampler:
+    """What the board reports WHILE the timed steps run (sysfs hwmon of the amdgpu card, every 10 ms from a thread of
+    its own; the main thread sits in a device synchronisation meanwhile): socket power, shader and memory clock.
+    Best effort, never fatal -- with the in-kernel step clock what is left to tell two boxes apart."""
+
+    def __init__(self, index):
+        import glob
+        self.h = None
+        try:
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+            if cards:
+                self.h = cards[min(index, len(cards) - 1)]
+        except Exception:
+            pass
+        self.rows, self._stop, self._t = [], False, None
+
+    def _rd(self, name, scale):
+        try:
+            return float(open(f"{self.h}/{name}").read().strip()) * scale
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop:
+            self.rows.append((self._rd("power1_average", 1e-6) or self._rd("power1_input", 1e-6),
+                              self._rd("freq1_input", 1e-6), self._rd("freq2_input", 1e-6), self._rd("temp1_input", 1e-3)))
+            time.sleep(0.01)
+
+    def __enter__(self):
+        if self.h:
+            import threading
+            self._t = threading.Thread(target=self._run, daemon=True)
+            self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._t:
+            self._t.join(timeout=1.0)
+
+    def summary(self):
+        def col(i):
+            v = [r[i] for r in self.rows if r[i] is not None]
+            return dict(mean=sum(v) / len(v), min=min(v), max=max(v)) if v else None
+        if not self.rows:
+            return None
+        return dict(samples=len(self.rows), power_w=col(0), sclk_mhz=col(1), mclk_mhz=col(2), temp_c=col(3),
+                    source=self.h, how="hwmon read every 10 ms while the timed steps ran")
+
+
 def source_hash():
     """sha256 over the sources the profiled kernels (basic front and back end) are compiled from, with comments and
     white space taken out: what the counter profile is valid for (a reworded comment does not make it stale, a
@@ -424,17 +474,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    sampled = {}                                           # advanced? -> what the board reported during the timed steps
+
     def run_steps(advanced, steps, warmup):
         """-> (seconds inside the timed regions, wall seconds, HIP-event timing of the last pass)"""
         if not waves_mode:
             for _ in range(warmup):
                 gstpeaq_amd.batch_run(ctx, advanced, ref, test, results=results, sync=False)
             barrier()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                gstpeaq_amd.batch_run(ctx, advanced, ref, test, results=results, sync=False)
-            barrier()
-            el = time.perf_counter() - t0
+            with DeviceSampler(local_rank) as smp:
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    gstpeaq_amd.batch_run(ctx, advanced, ref, test, results=results, sync=False)
+                barrier()
+                el = time.perf_counter() - t0
+            sampled[bool(advanced)] = smp.summary()
             return el, el, ctx.last_timing()
         # waves: the resident buffers hold wave 0 on entry; a warm-up step runs that wave only
         for _ in range(warmup):
@@ -472,7 +526,13 @@ def main():
         return dict(timed=timed, wall=wall, timing=timing, gathered=gathered, fp_all=frame_pairs_all, gather_ms=gather_ms,
                     fp_rank=frame_pairs_rank, rows=results[: min(4096, hi - lo)].cpu().numpy().copy())
 
-    def frontend_roofline(m, advanced):
+    def simd_cycles_per_s(clock_mhz):
+        """SIMDs x the shader clock THIS run measured (compute units from peaq_calibrate, the clock of the step itself);
+        the constants 1024 x 2.4 GHz only if neither is known"""
+        cus = (cal0 or {}).get("compute_units") or 256
+        return cus * 4 * (clock_mhz * 1e6 if clock_mhz else 2.4e9)
+
+    def frontend_roofline(m, advanced, clock_mhz=None):
         timing = m["timing"]
         # HIP events of the LAST batch call (one wave in waves mode) on the launch stream
         last_pairs = wave_pairs if waves_mode else pairs_per_gpu
@@ -483,19 +543,21 @@ def main():
         achieved = fp_last * ALGO_BYTES_PER_FRAME_PAIR / fe_s / 1e9 if fe_s > 0 else 0.0
         prof = profile_numbers()
         valu_frac = step_valu_frac = None
-        if prof.get("valu_per_wave") and not advanced and fe_s > 0:
+        stale = bool((prof.get("from_profile") or {}).get("stale"))
+        if prof.get("valu_per_wave") and not advanced and fe_s > 0 and not stale:   # (a stale profile prices nothing)
             # One issue model everywhere: an FP64 vector instruction occupies a SIMD for 4 cycles
             # per wave, every other one for 2 (MI355X_MICROARCH.md: SIMD-32, FP64 at half the FP32 rate;
-            # profiles/r02_microbench.txt measures 4.5-5.4 and 2.4-2.9 for back-to-back FMAs); 1024 SIMDs, 2.4 GHz.
+            # profiles/r02_microbench.txt measures 4.5-5.4 and 2.4-2.9 for back-to-back FMAs); the device's SIMDs at
+            # the shader clock the step itself measured (simd_cycles_per_s).
             # Instruction counts per wave from the committed counter profile, times from THIS run's HIP events.
             f64 = prof.get("fp64_per_wave") or 0.0
             cyc = f64 * 4 + (prof["valu_per_wave"] - f64) * 2
-            fe_issue_s = fp_last * args.channels * 2 * cyc / (1024 * 2.4e9)
+            fe_issue_s = fp_last * args.channels * 2 * cyc / simd_cycles_per_s(clock_mhz)
             valu_frac = fe_issue_s / fe_s
             if prof.get("be_valu_per_wave_frame") and timing["total_ms"] > 0:
                 b64 = prof.get("be_fp64_per_wave_frame") or 0.0
                 be_cyc = b64 * 4 + (prof["be_valu_per_wave_frame"] - b64) * 2
-                be_issue_s = fp_last * args.channels * be_cyc / (1024 * 2.4e9)
+                be_issue_s = fp_last * args.channels * be_cyc / simd_cycles_per_s(clock_mhz)
                 step_valu_frac = (fe_issue_s + be_issue_s) / (timing["total_ms"] * 1e-3)
         launches = max(timing["frontend_launches"], 1)
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -506,14 +568,16 @@ def main():
                 "compute_frac_fp64_vector": fp_last / fe_s * FLOP_PER_FRAME_PAIR / (FP64_VECTOR_PEAK_TFLOPS * 1e12)
                 if fe_s > 0 else None,
                 "valu_issue_frac": valu_frac, "step_valu_issue_frac": step_valu_frac,
-                "valu_issue_model": "4 cycles per FP64 vector instruction and wave, 2 per other vector instruction; "
+                "valu_issue_clock_mhz": clock_mhz,
+                "valu_issue_model": "4 cycles per FP64 vector instruction and wave, 2 per other vector instruction, SIMDs x the "
+                                    "step's own shader clock (null if the counter profile is stale); "
                                     "kernel: front-end instructions / front-end kernel time; step: front + back end / "
                                     "whole step (HIP events of this run; instruction counts per wave from_profile)",
                 "from_profile": prof["from_profile"],
                 "from_profile_fields": ["traffic", "valu_issue_frac", "step_valu_issue_frac"],
                 "backend_ms": timing["backend_ms"], "fb_ms": timing["fb_ms"], "step_ms_events": timing["total_ms"]}
 
-    def filterbank_roofline(m):
+    def filterbank_roofline(m, clock_mhz=None):
         # configs[2]: the dominant kernel is the filter bank (fb_bank_kernel), a folded FIR bank on the
         # matrix cores.  Algorithmic work as the reference counts it (fbearmodel.c:404-434): per tap
         # pair two additions and two multiply-adds, 10 914 tap pairs per sub-sample, 6 sub-samples per
@@ -521,7 +585,11 @@ def main():
         timing = m["timing"]
         last_pairs = wave_pairs if waves_mode else pairs_per_gpu
         blocks = float(results[:last_pairs, 15].sum().item())
-        flops = blocks * args.channels * 2 * 6 * 10914 * 6
+        # 21 828 multiply-adds per sub-sample and signal (10 914 folded tap pairs x {re, im}) = the
+        # ALGORITHMIC work `achieved` is quoted in; the reference's own loop spends 65 484 flop on them (two additions
+        # and two multiply-adds per tap pair, fbearmodel.c:404-434): `reference_operation_frac`
+        flops = blocks * args.channels * 2 * 6 * 21828 * 2
+        ref_flops = blocks * args.channels * 2 * 6 * 10914 * 6
         fb_s = timing["fb_ms"] * 1e-3
         tf = flops / fb_s / 1e12 if fb_s > 0 else 0.0
         mode = ctx.fir_mode()
@@ -542,25 +610,28 @@ def main():
             # kernel's time from THIS run's HIP events; 1024 SIMDs at 2.4 GHz
             bp = bank_profile_numbers()
             simd_busy = None
-            if bp and fb_s > 0:
+            if bp and fb_s > 0 and not bp["from_profile"]["stale"]:      # (a stale profile prices nothing)
                 cyc = bp["valu_fp64_per_wave_block"] * 4 + (bp["valu_per_wave_block"] - bp["valu_fp64_per_wave_block"]) * 2 \
                     + bp["mfma_per_wave_block"] * 64
-                simd_busy = blocks * args.channels * 2 * 4 * cyc / (1024 * 2.4e9) / fb_s
+                simd_busy = blocks * args.channels * 2 * 4 * cyc / simd_cycles_per_s(clock_mhz) / fb_s
             extra = {"simd_busy_frac": simd_busy, "simd_busy_from_profile": bp and bp["from_profile"],
-                     "reference_flop_per_subsample": 10914 * 6, "matrix_flop_per_subsample": (24 * 8 * 32 + 30 * 4 * 16 * 2) * 2,
+                     "simd_busy_clock_mhz": clock_mhz,
+                     "simd_busy_is": "(4 x FP64 vector + 2 x other vector + 64 x matrix instructions per wave) x waves / (SIMDs x "
+                                     "the step's own shader clock x kernel time); instruction counts from the committed counter "
+                                     "profile, null if that profile is stale",
+                     "reference_flop_per_subsample": 10914 * 6, "algorithmic_flop_per_subsample": 21828 * 2,
+                     "matrix_flop_per_subsample": (24 * 8 * 32 + 30 * 4 * 16 * 2) * 2,
                      "matrix_flop_per_launch": issued / max(timing["fb_launches"], 1),
                      "matrix_pipe_frac": issued / fb_s / 1e12 / peak if fb_s > 0 else None,
                      "algorithm": "block-sum form: bands 0..23 as running sums over 32-sample blocks (Hann window = three "
                                   "rectangular windows), bands 24..39 direct; fbearmodel.c:399-435"}
-        # `frac`: for the FP64 engine the SIMD-busy fraction (the kernel issues a third of the multiply-adds the reference's
-        # operation count credits it with, so achieved / peak is an algorithm-equivalent rate, not a utilisation -- it
-        # stays in the line as `algorithm_equivalent_frac`); for the other engines achieved / peak as before
-        frac = extra.get("simd_busy_frac") if mode == "f64" and extra.get("simd_busy_frac") else tf / peak
+        # `frac` = achieved / peak in every engine, with `achieved` = SURVEY.md 8(d)'s algorithmic multiply-adds over
+        # this kernel's time (what the block-sum form is credited with: it issues fewer); what the SIMDs are busy
+        # with stands beside it as `simd_busy_frac`, the matrix pipe's own share as `matrix_pipe_frac`
         return {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
-                "frac": frac, "algorithm_equivalent_frac": tf / peak,
-                "frac_is": ("SIMD-busy fraction: (4 x FP64 vector + 2 x other vector + 64 x matrix instructions per wave) x waves "
-                            "/ (1024 SIMDs x 2.4 GHz x kernel time)" if mode == "f64" and extra.get("simd_busy_frac")
-                            else "achieved / peak"),
+                "frac": tf / peak, "frac_is": "achieved / peak; achieved = 21 828 multiply-adds per sub-sample and signal "
+                                              "(SURVEY.md 8(d)) x 2 / kernel time",
+                "reference_operation_frac": ref_flops / fb_s / 1e12 / peak if fb_s > 0 else None,
                 "traffic": None, **extra,
                 "kernel": {"f64": "fb_bank_kernel<MfmaF64>", "f32": "fb_bank_kernel<MfmaF32>", "f16x3": "fb_bank_kernel<MfmaH3>"}[mode],
                 "peak_is": {"f64": "FP64 matrix = vector peak", "f32": "FP32 matrix peak (f32-input MFMA), MI355X_MICROARCH.md",
@@ -611,7 +682,7 @@ def main():
                        "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
                        "result_gather": f"{dist.get_backend()} all_gather over {dist.get_world_size()} rank(s)" if dist
                        else "none (one process)"},
-            "roofline": filterbank_roofline(m) if main_adv else frontend_roofline(m, False),
+            "roofline": filterbank_roofline(m, step_clock_mhz) if main_adv else frontend_roofline(m, False, step_clock_mhz),
             "odg_mean": float(odg[~torch.isnan(odg)].mean().item()),
             "odg_nan": int(torch.isnan(odg).sum().item()),
         }
@@ -620,11 +691,13 @@ def main():
         line["device_clock"] = {
             "step_shader_clock_mhz": step_clock_mhz,
             "calibration_before": cal0, "calibration_after": cal1, "nominal_mhz": nominal,
-            "power": device_power_info(local_rank),
+            "power": device_power_info(local_rank), "board_during_steps": sampled.get(main_adv),
             "how": "step clock: workgroup 0 of every back-end launch of the last timed pass reads the shader-clock and the "
                    "constant-rate counter around its lifetime, beside the front end of the next chunk (peaq_batch_last_clock); "
-                   "calibration: peaq_calibrate, a fixed v_fma_f64 kernel (two waves per SIMD) before and after the timed "
-                   "region; rank 0's device"}
+                   "calibration: peaq_calibrate, a fixed v_fma_f64 kernel (one wave per SIMD, sixteen chains, ~70 ms, alone on the device) "
+                   "before and after the timed region -- its second half is the steady state (shader_clock_mhz, fp64_tflops, "
+                   "cycles_per_fma: 4 = the FP64 pipe), its first half the ramp from the idle clock "
+                   "(ramp_*); rank 0's device"}
         # the same line at the device's nominal clock: the path is issue-bound, its time scales with 1 / clock
         line["value_at_nominal_clock"] = value * nominal / step_clock_mhz if step_clock_mhz else None
         line["result_gather_ms"] = m["gather_ms"]           # after the timed region; 128 B per pair
@@ -657,7 +730,7 @@ def main():
                        "fb_blocks_per_frame_pair": float(m64["gathered"][:, 15].sum().item()) / max(m64["fp_all"], 1.0),
                        "dtype": "f64 (every stage, like the reference; FIR bank of the filter-bank ear model on v_mfma_f64_16x16x4_f64)",
                        "engine": "PEAQ_FIR_F64: the engine's default (peaq_ctx_create); the opt-in fast engine is reduced_precision_f16x3",
-                       "roofline": filterbank_roofline(m64),
+                       "roofline": filterbank_roofline(m64, adv_clock), "board_during_steps": sampled.get(True),
                        "odg_mean": float(m64["gathered"][:, 12][~torch.isnan(m64["gathered"][:, 12])].mean().item())}
             rows_adv = m64["rows"]
         except Exception as e:                               # the bench line must survive this leg
@@ -676,7 +749,7 @@ def main():
                                     "products per term, FP32 accumulation), slopes and upward spreading FP32, everything else "
                                     "FP64: narrower than the reference's arithmetic, hence opt-in and not the headline",
                            "engine": "PEAQ_FIR_F16X3 (peaq_ctx_set_fir_mode / PEAQ_AMD_FIR=f16x3); NOT the default",
-                           "roofline": filterbank_roofline(ma)}
+                           "roofline": filterbank_roofline(ma, ctx.last_clock_mhz())}
                     if rows_adv is not None:
                         a, b = ma["rows"][:, 12], rows_adv[:, 12]
                         ok = ~(np.isnan(a) | np.isnan(b))

@@ -31,7 +31,8 @@ class PeaqError(RuntimeError):
 
 class _Calibration(C.Structure):
     _fields_ = [("elapsed_ms", C.c_double), ("shader_clock_mhz", C.c_double), ("fp64_tflops", C.c_double),
-                ("cycles_per_fma", C.c_double), ("max_clock_mhz", C.c_double), ("compute_units", C.c_int)]
+                ("cycles_per_fma", C.c_double), ("max_clock_mhz", C.c_double), ("compute_units", C.c_int),
+                ("ramp_clock_mhz", C.c_double), ("ramp_cycles_per_fma", C.c_double), ("event_fp64_tflops", C.c_double)]
 
 
 class _Timing(C.Structure):
@@ -128,6 +129,8 @@ def load_library():
     L.peaq_broker_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, C.c_int,
                                            C.POINTER(vp)]
     L.peaq_broker_devices.argtypes = [vp]
+    if hasattr(L, "peaq_debug_broker_fail_shard"):
+        L.peaq_debug_broker_fail_shard.argtypes = [vp, C.c_int, C.c_char_p]
     L.peaq_broker_stats_size.argtypes = []
     L.peaq_broker_stats_size.restype = C.c_size_t
     L.peaq_broker_destroy.argtypes = [vp]
@@ -296,6 +299,10 @@ class Broker:
 
     def devices(self):
         return int(self.L.peaq_broker_devices(self.h))
+
+    def fail_shard(self, shard, message):
+        """test hook (peaq_debug_broker_fail_shard): one device's share stops as after a device error"""
+        _check(self.L.peaq_debug_broker_fail_shard(self.h, int(shard), message.encode()))
 
     def open(self):
         sid = C.c_int(-1)

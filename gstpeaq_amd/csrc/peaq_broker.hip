@@ -576,6 +576,24 @@ extern "C" int peaq_broker_create_multi(const int* devices, int n_devices, int a
   return PEAQ_OK;
 }
 
+// Test hook (include/peaq_amd.h): shard `shard` of a multi-device broker (0 of a plain one) is put into the state a
+// device error during one of its ticks leaves it in -- failed for good, with `message` as the error it keeps.
+extern "C" int peaq_debug_broker_fail_shard(peaq_broker* b, int shard, const char* message) {
+  if (!b) return fail(PEAQ_ERR_ARG, "peaq_debug_broker_fail_shard: broker is NULL");
+  peaq_broker* sh = b;
+  if (broker_is_multi(b)) {
+    if (shard < 0 || shard >= (int)b->shards.size()) return fail(PEAQ_ERR_ARG, "peaq_debug_broker_fail_shard: no such shard");
+    sh = b->shards[shard];
+  } else if (shard != 0) {
+    return fail(PEAQ_ERR_ARG, "peaq_debug_broker_fail_shard: no such shard");
+  }
+  std::lock_guard<std::mutex> tick(sh->tick_mu);
+  std::lock_guard<std::mutex> e(sh->err_mu);
+  sh->worker_error = message ? message : "injected fault";
+  sh->failed.store(true);
+  return PEAQ_OK;
+}
+
 extern "C" int peaq_broker_devices(const peaq_broker* b) { return !b ? 0 : broker_is_multi(b) ? (int)b->shards.size() : 1; }
 extern "C" size_t peaq_broker_stats_size(void) { return sizeof(peaq_broker_stats_t); }
 

@@ -244,76 +244,111 @@ extern "C" int peaq_debug_frontend_profile(peaq_ctx* c, unsigned long long* out6
 // ---------------------------------------------------------------------------
 // device calibration: what the GPU clocks at under an FP64 load, and what FP64 rate that gives
 // ---------------------------------------------------------------------------
-// Two waves per SIMD run eight independent chains of v_fma_f64 each; one lane of every workgroup reads the shader
-// clock (s_memtime) and the constant 100 MHz counter around its chain.  The chip clocks to its power budget
-// (MI355X_MICROARCH.md, "DVFS give-back"), and PEAQ's FP64-dense kernels sit at that budget: two boxes -- or one box
-// at two moments -- differ by several per cent in the same library's frame-pairs/s.  bench.py runs this before and
-// after its timed region so that the line says which.
+// ONE wave per SIMD runs sixteen independent chains of v_fma_f64; one lane of every workgroup reads the shader clock
+// (s_memtime) and the constant 100 MHz counter at the start, in the MIDDLE and at the end of its chain.  The chip
+// clocks to its power budget (MI355X_MICROARCH.md, "DVFS give-back"), and PEAQ's FP64-dense kernels sit at that budget:
+// two boxes -- or one box at two moments -- differ by several per cent in the same library's frame-pairs/s.  bench.py
+// runs this before and after its timed region so that the line says which.  The kernel starts from whatever clock the
+// idle device held: the FIRST half of the run is reported as the ramp, the SECOND half -- tens of milliseconds in --
+// as the steady state.  (Rounds 5 and, at first, 6 ran TWO waves per SIMD with eight chains each and read "8 cycles per
+// multiply-add and wave = the pipe's 4" into it; measured over 70 ms: 9.06 in the first half, 4.69 in the second, a
+// kernel that lasts twice a wave's lifetime -- a SIMD issues from its OLDEST ready wave first, so with always-ready
+// chains the two waves run one after the other, not side by side, and per-wave times say nothing about the device's
+// rate.  One wave per SIMD has no partner to be confused with: its 4.0x cycles per multiply-add ARE the pipe's.)
 namespace {
 __global__ __launch_bounds__(64) void calib_kernel(double* out, unsigned long long* ticks, int iters) {
-  double a0 = threadIdx.x * 1e-3, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
-  const double b = 1.0000001, c = 1e-9;
-  const unsigned long long w0 = wall_clock64(), c0 = __builtin_readcyclecounter();
-  for (int i = 0; i < iters; ++i) {
+  double a[16];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      a0 = fma(a0, b, c); a1 = fma(a1, b, c); a2 = fma(a2, b, c); a3 = fma(a3, b, c);
-      a4 = fma(a4, b, c); a5 = fma(a5, b, c); a6 = fma(a6, b, c); a7 = fma(a7, b, c);
+  for (int k = 0; k < 16; ++k) a[k] = threadIdx.x * 1e-3 + k;
+  const double b = 1.0000001, c = 1e-9;
+  unsigned long long w[3], cy[3];
+  w[0] = wall_clock64();
+  cy[0] = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll 1
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = fma(a[k], b, c);
+      }
     }
+    cy[half + 1] = __builtin_readcyclecounter();
+    w[half + 1] = wall_clock64();
   }
-  const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
-  out[blockIdx.x * 64 + threadIdx.x] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  double sum = 0.;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) sum += a[k];
+  out[blockIdx.x * 64 + threadIdx.x] = sum;
   if (threadIdx.x == 0) {
-    ticks[2 * blockIdx.x] = c1 - c0;
-    ticks[2 * blockIdx.x + 1] = w1 - w0;
+    ticks[4 * blockIdx.x] = cy[1] - cy[0];
+    ticks[4 * blockIdx.x + 1] = w[1] - w[0];
+    ticks[4 * blockIdx.x + 2] = cy[2] - cy[1];
+    ticks[4 * blockIdx.x + 3] = w[2] - w[1];
   }
 }
+constexpr int kCalibFmasPerIter = 512;               // 16 chains x 32 (the loop's own ~ 40 cycles per trip: 2 % of 2048)
 }  // namespace
 
 extern "C" int peaq_calibrate(peaq_ctx* c, int iterations, peaq_calibration* out) {
   if (!c || !out) return fail(PEAQ_ERR_ARG, "peaq_calibrate: NULL argument");
-  if (iterations <= 0) iterations = 20000;           // x 64 FMAs per wave: about 5 ms
+  if (iterations <= 0) iterations = 80000;           // x 512 multiply-adds per wave: about 70 ms, the clock has settled by half-way
+  const int half = (iterations + 1) / 2;
   std::lock_guard<std::mutex> lock(c->mu);
   HIP_TRY(hipSetDevice(c->device));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, c->device));
   int wall_khz = 100000;
   (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, c->device);
-  const int waves = prop.multiProcessorCount * 4 * 2;   // two per SIMD
+  const int waves = prop.multiProcessorCount * 4;      // one per SIMD
   TmpBuf sink, ticks;
   HIP_TRY(sink.reserve((size_t)waves * 64 * sizeof(double)));
-  HIP_TRY(ticks.reserve((size_t)waves * 2 * sizeof(unsigned long long)));
-  if (c->batch_pending) HIP_TRY(hipEventSynchronize(c->batch_end));   // a batch still running would share the device with the probe
-  hipLaunchKernelGGL(calib_kernel, dim3(waves), dim3(64), 0, 0, sink.as<double>(), ticks.as<unsigned long long>(), 200);   // warm
-  struct Events {                                    // destroyed on every way out
+  HIP_TRY(ticks.reserve((size_t)waves * 4 * sizeof(unsigned long long)));
+  // "The clock under a fixed load" means NOTHING else on the device: this context's batch, and whatever its sessions,
+  // brokers or other contexts of the process still have in flight (their streams do not synchronise with ours).
+  // Work of OTHER processes on the device cannot be seen from here: the caller's responsibility (include/peaq_amd.h).
+  HIP_TRY(hipDeviceSynchronize());
+  struct Scope {                                     // destroyed on every way out
     hipEvent_t a = nullptr, b = nullptr;
-    ~Events() {
+    hipStream_t s = nullptr;
+    ~Scope() {
       if (a) (void)hipEventDestroy(a);
       if (b) (void)hipEventDestroy(b);
+      if (s) (void)hipStreamDestroy(s);
     }
-  } ev;
-  HIP_TRY(hipEventCreate(&ev.a));
-  HIP_TRY(hipEventCreate(&ev.b));
-  HIP_TRY(hipEventRecord(ev.a, 0));
-  hipLaunchKernelGGL(calib_kernel, dim3(waves), dim3(64), 0, 0, sink.as<double>(), ticks.as<unsigned long long>(), iterations);
+  } sc;
+  HIP_TRY(hipStreamCreateWithFlags(&sc.s, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&sc.a));
+  HIP_TRY(hipEventCreate(&sc.b));
+  HIP_TRY(hipEventRecord(sc.a, sc.s));
+  hipLaunchKernelGGL(calib_kernel, dim3(waves), dim3(64), 0, sc.s, sink.as<double>(), ticks.as<unsigned long long>(), half);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(ev.b, 0));
-  HIP_TRY(hipEventSynchronize(ev.b));
+  HIP_TRY(hipEventRecord(sc.b, sc.s));
+  HIP_TRY(hipEventSynchronize(sc.b));
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
-  std::vector<unsigned long long> h((size_t)waves * 2);
+  HIP_TRY(hipEventElapsedTime(&ms, sc.a, sc.b));
+  std::vector<unsigned long long> h((size_t)waves * 4);
   HIP_TRY(hipMemcpy(h.data(), ticks.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  double shader = 0., wall = 0.;
-  for (int i = 0; i < waves; ++i) {
-    shader += (double)h[2 * i];
-    wall += (double)h[2 * i + 1];
-  }
-  const double fmas = (double)waves * 64. * 64. * iterations;   // lanes x FMAs per iteration
+  double shader[2] = {0., 0.}, wall[2] = {0., 0.};
+  for (int i = 0; i < waves; ++i)
+    for (int k = 0; k < 2; ++k) {
+      shader[k] += (double)h[4 * i + 2 * k];
+      wall[k] += (double)h[4 * i + 2 * k + 1];
+    }
+  const double fmas_half = (double)waves * 64. * kCalibFmasPerIter * half;   // lanes x multiply-adds per iteration x iterations
+  const double wall_hz = wall_khz * 1e3;
+  auto mhz = [&](int k) { return wall[k] > 0. ? shader[k] / wall[k] * (wall_khz * 1e-3) : 0.; };
+  auto cpf = [&](int k) { return shader[k] / ((double)waves * kCalibFmasPerIter * half); };   // per wave = per SIMD
   out->elapsed_ms = ms;
-  out->shader_clock_mhz = wall > 0. ? shader / wall * (wall_khz * 1e-3) : 0.;
-  out->fp64_tflops = ms > 0.f ? 2. * fmas / (ms * 1e-3) * 1e-12 : 0.;
-  out->cycles_per_fma = shader / ((double)waves * 64. * iterations);   // per wave, two waves sharing a SIMD
+  out->shader_clock_mhz = mhz(1);
+  // all waves run at once, each alone on its SIMD: the rate is the half's work over the MEAN duration of a wave's second half
+  out->fp64_tflops = wall[1] > 0. ? 2. * fmas_half / (wall[1] / waves / wall_hz) * 1e-12 : 0.;
+  out->cycles_per_fma = cpf(1);
   out->compute_units = prop.multiProcessorCount;
   out->max_clock_mhz = prop.clockRate * 1e-3;
+  out->ramp_clock_mhz = mhz(0);
+  out->ramp_cycles_per_fma = cpf(0);
+  out->event_fp64_tflops = ms > 0.f ? 4. * fmas_half / (ms * 1e-3) * 1e-12 : 0.;
   return PEAQ_OK;
 }

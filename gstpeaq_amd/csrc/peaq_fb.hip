@@ -1178,9 +1178,13 @@ __device__ __forceinline__ void spread_up(BankLds<WT>& sh, const double (&re)[10
 // The FP64 engine's upward spreading, dealt to the waves by TARGET: wave W owns the bands j = W, W + 4, W + 8, ...
 // (j >= 1) and sums, per time point = lane, what every lower band sends there -- all sources' outputs and slopes come
 // from LDS (A, and the slope exchange cux), the ten sums stay in registers until every wave has read its sources.
-// One wave, one sequential sum per element: the result does not depend on the order in which the waves run, and two
-// runs agree bit for bit; spread_up above has the four waves add their partial sums into A with LDS atomics in
-// whatever order they arrive (kept for the reduced-precision engines).  A source's terms at the owned targets are
+// One wave, one sum in one fixed order per element: the result does not depend on the order in which the waves run, and
+// two RUNS agree bit for bit (that, not more: against the reference's loop, fbearmodel.c:340-348, the order differs --
+// a band's own output joins its sum when its turn as a source comes, after the lower bands' terms, and a source's
+// powers are formed as c^2, c^4, c^2 c and steps of c^4 rather than by repeated multiplication -- so the last bits
+// differ from the oracle's as any other reordering's would; the tests hold the blocks to 1e-9).  spread_up above has
+// the four waves add their partial sums into A with LDS atomics in whatever order they arrive (kept for the
+// reduced-precision engines).  A source's terms at the owned targets are
 // four bands apart: its tail starts at cu^r (r = 1 .. 4 bands up to the first owned target) and moves on by cu^4.
 template <int W, typename CUX>
 __device__ __forceinline__ void spread_up_owned(const double (*are)[kACols], const double (*aim)[kACols], CUX cux, int lane,

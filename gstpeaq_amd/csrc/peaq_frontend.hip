@@ -706,7 +706,11 @@ void frontend_kernel(FrontendArgs a) {
           }
           far[s] = ene[s] * pw;
         }
-        back2[s] = div_fast(1., t2 * t2);
+        // (a^-0.8; 0 where a^0.8 underflows -- never with finite samples, the internal noise bounds Pp from below -- so
+        // that such a source sends nothing instead of 0 x inf: the walk's rounding, ~ kLanes ulp on the near terms and
+        // ~ 1e-14 relative in all, is DESIGN.md 3's)
+        const double t4 = t2 * t2;
+        back2[s] = t4 > 1e-290 ? div_fast(1., t4) : 0.;
       } else {
         ae[s] = 0.;
         ene[s] = 0.;

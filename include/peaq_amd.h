@@ -202,6 +202,12 @@ int  peaq_broker_create_multi (const int *devices, int n_devices, int advanced, 
                                double playback_level_db, int max_sessions, const peaq_settings *settings,
                                int fir_mode, peaq_broker **out);
 int  peaq_broker_devices (const peaq_broker *b);                       /* 1 for peaq_broker_create's */
+/* Test hook: puts one device's share of a multi-device broker (shard 0 .. devices - 1 in the order of `devices`; 0 of a
+ * plain broker) into the state a device error during one of its ticks leaves it in -- stopped for good, `message` kept
+ * as its error.  What must hold then (tests/test_gpu_broker.py): peaq_broker_tick still ticks every other device and
+ * returns this device's error; sessions on the other devices run to their results; every call on a session of the
+ * failed device reports that device's own message. */
+int  peaq_debug_broker_fail_shard (peaq_broker *b, int shard, const char *message);
 void peaq_broker_destroy (peaq_broker *b);
 int  peaq_broker_open    (peaq_broker *b, int *session_id);            /* gst_peaq_init / READY->PAUSED      */
 int  peaq_broker_close   (peaq_broker *b, int session_id);             /* finalize                           */
@@ -260,18 +266,24 @@ int peaq_run_pair (peaq_ctx *ctx, int advanced, int channels, double playback_le
                    const float *ref, size_t n_ref, const float *test, size_t n_test, peaq_result *out);
 
 /* ---- device calibration (measurement support, bench.py) -----------------------
- * Runs a fixed FP64 multiply-add kernel (two waves per SIMD, eight independent chains each; `iterations` x 64
- * multiply-adds per wave, <= 0: about 5 ms) on the context's device and reports the shader clock the device held
- * under that load and the FP64 rate it gave.  MI355X clocks to its power budget, and this path's kernels are
- * FP64-dense: the same library differs by several per cent from box to box.  bench.py calls this before and after
- * its timed region so that a throughput line carries the clock it was measured at. */
+ * Runs a fixed FP64 multiply-add kernel (ONE wave per SIMD, sixteen independent chains; `iterations` x 512
+ * multiply-adds per wave, <= 0: about 70 ms) on the context's device -- alone: it waits for everything this PROCESS has
+ * in flight on the device first (hipDeviceSynchronize) and runs on a stream of its own; work of other processes on the
+ * same device is the caller's to exclude -- and reports the shader clock the device held under that load and the FP64
+ * rate it gave.  MI355X clocks to its power budget, and this path's kernels are FP64-dense: the same library differs
+ * by several per cent from box to box.  bench.py calls this before and after its timed region so that a throughput
+ * line carries the clock it was measured at.  The kernel starts from the idle device's clock: its FIRST half is
+ * reported as the ramp (ramp_*), its SECOND half as the steady state (the unprefixed fields). */
 typedef struct {
-  double elapsed_ms;          /* HIP events around the kernel */
-  double shader_clock_mhz;    /* s_memtime ticks / constant-rate wall-clock ticks, mean over all waves */
-  double fp64_tflops;         /* 2 x multiply-adds issued / elapsed */
-  double cycles_per_fma;      /* shader cycles per v_fma_f64 and wave (two waves share a SIMD: 8 = the pipe's 4) */
+  double elapsed_ms;          /* HIP events around the whole kernel (both halves) */
+  double shader_clock_mhz;    /* steady state: s_memtime ticks / constant-rate wall-clock ticks, mean over all waves */
+  double fp64_tflops;         /* steady state: 2 x the half's multiply-adds / mean duration of a wave's second half */
+  double cycles_per_fma;      /* steady state: shader cycles per v_fma_f64 of a wave that has its SIMD to itself (4 = the pipe) */
   double max_clock_mhz;       /* hipDeviceProp_t::clockRate */
   int    compute_units;
+  double ramp_clock_mhz;      /* the same over the first half: from the idle clock upwards, waves still being dispatched */
+  double ramp_cycles_per_fma;
+  double event_fp64_tflops;   /* 2 x all multiply-adds / elapsed_ms: includes launch, ramp and tail */
 } peaq_calibration;
 int peaq_calibrate (peaq_ctx *ctx, int iterations, peaq_calibration *out);
 

@@ -153,3 +153,50 @@ def test_broker_argument_and_state_errors():
     with pytest.raises(gstpeaq_amd.PeaqError):
         gstpeaq_amd.Broker(gpu.ctx(), 1, max_sessions=0)
     b.close()
+
+
+@pytest.mark.parametrize("advanced", [False, True], ids=["basic", "advanced"])
+def test_one_failed_device_of_a_multi_device_broker_does_not_starve_the_others(advanced):
+    """peaq_broker_create_multi over {0, 0} (two contexts, two sets of slots on the one GPU of the box) with the second
+    device's share stopped as after a device error in one of its ticks (peaq_debug_broker_fail_shard): the tick still
+    launches the other device's frames and returns the failed device's own message; sessions on the healthy device run
+    to the batch path's results; every call on a session of the failed device reports THAT device's error."""
+    import gstpeaq_amd
+    channels, n = 2, 8
+    streams = _streams(n, channels)
+    whole = gpu.run_batch(streams, advanced, channels)
+    b = gstpeaq_amd.Broker(gpu.ctx(), channels, max_sessions=8, advanced=advanced, devices=[0, 0])
+    assert b.devices() == 2
+    sids = [b.open() for _ in range(n)]
+    shard_of = [s % 2 for s in sids]                    # session id = shard + 2 x the shard's own id (peaq_broker.hip)
+    assert sorted(shard_of) == [0] * 4 + [1] * 4         # dealt out evenly
+    rng = np.random.default_rng(9)
+    half = [len(r) // 2 for r, _ in streams]
+    for i, (ref, test) in enumerate(streams):            # first half of every stream, then a tick of both devices
+        b.push(sids[i], 0, ref[:half[i]])
+        b.push(sids[i], 1, test[:half[i]])
+    assert b.tick() >= 1                                # (both devices launch what their sessions have ready)
+    b.fail_shard(1, "injected: device 1 fell off the bus")
+    with pytest.raises(gstpeaq_amd.PeaqError, match="device 1 fell off the bus"):
+        b.tick()                                         # ... which has ticked device 0 all the same (nothing ready there: fine)
+    for i, (ref, test) in enumerate(streams):
+        if shard_of[i] == 1:
+            with pytest.raises(gstpeaq_amd.PeaqError, match="device 1 fell off the bus"):
+                b.push(sids[i], 0, ref[half[i]:])
+            with pytest.raises(gstpeaq_amd.PeaqError, match="device 1 fell off the bus"):
+                b.flush(sids[i])
+            continue
+        _feed_rest = [(0, ref[half[i]:]), (1, test[half[i]:])]
+        for pad, sig in _feed_rest:
+            pos = 0
+            while pos < len(sig):
+                k = int(rng.integers(1, 6000))
+                b.push(sids[i], pad, sig[pos:pos + k])
+                pos += k
+        b.flush(sids[i])
+    with pytest.raises(gstpeaq_amd.PeaqError, match="device 1 fell off the bus"):
+        b.tick()                                         # the healthy device's flush frames go out in this very call
+    for i in range(n):
+        if shard_of[i] == 0:
+            _same(b.results(sids[i]), whole[i], i, rtol=gpu.tol("chunks") if advanced else 1e-12)
+    b.close()

@@ -72,3 +72,30 @@ def test_bench_gpus_2_launches_its_own_ranks(tmp_path):
     assert line["config"]["result_gather"] == "gloo all_gather over 2 rank(s)"
     a = np.load(dump)
     assert a.shape == (192, 16) and len(np.unique(a[:, 12])) > 150 and line["odg_nan"] == 0
+
+
+def test_two_ranks_advanced_version_equal_one_process(tmp_path):
+    """The same for configs[2]'s arithmetic: `--advanced` (the filter-bank path's three streams, its chunked rows and
+    records per rank) on two real ranks sharing the box's GPU; the gathered records equal the one-process run's bit for
+    bit (the default FP64 engine is bit-reproducible) -- and the line carries the advanced roofline."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (there is no CPU fallback in the product)")
+    two, one = tmp_path / "two_adv.npy", tmp_path / "one_adv.npy"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env2 = dict(env, PEAQ_BENCH_DIST_BACKEND="gloo", PEAQ_BENCH_DUMP_RESULTS=str(two), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "1", "--warmup", "1", "--seconds", "2", "--wave-pairs", "32", "--no-cpu-baseline"]
+    # (64 pairs per rank in waves of 32, 128 in waves of 32 in the one process: every launch holds 32 pairs in both,
+    # so the filter bank's chunks of blocks are cut alike -- what "bit for bit" needs across differently cut streams
+    # is stated in tests/gpu_common.py, "chunks")
+    line2 = run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--advanced", "--pairs", "64"] + common, env2)
+    env1 = dict(env, PEAQ_BENCH_DUMP_RESULTS=str(one))
+    run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--advanced", "--waves", "--pairs", "128",
+         "--no-scaling-reference"] + common, env1)
+    a, b = np.load(two), np.load(one)
+    assert a.shape == b.shape == (128, 16)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), "gathered advanced records differ from the one-process run"
+    assert len(np.unique(a[:, 12])) > 100 and (a[:, 15] > 0).all()        # filter-bank blocks were counted for every pair
+    assert line2["n_gpus"] == 2 and line2["config"]["total_pairs"] == 128 and line2["config"]["waves_per_step"] == 2
+    assert line2["roofline"]["kernel"] == "fb_bank_kernel<MfmaF64>" and line2["roofline"]["bound"] == "mfma"
+    assert line2["roofline"]["frac"] == pytest.approx(line2["roofline"]["achieved"] / line2["roofline"]["peak"])
