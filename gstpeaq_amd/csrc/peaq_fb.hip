@@ -354,6 +354,9 @@ __global__ __launch_bounds__(64 * kHpWaves) void fb_hp_kernel(FbFrontArgs a, uns
 // that the four waves carry the same number of taps.  Phases 2..5 turn the 40 x 60
 // filter outputs into excitation patterns.
 // ---------------------------------------------------------------------------
+#ifndef PEAQ_FB_OLD_NEXT_MAP
+#define PEAQ_FB_OLD_NEXT_MAP 0                       // (development: 1 = round 5's sample-major hand-over of the next window)
+#endif
 constexpr int kTileSub = 60;                        // sub-samples per tile (10 blocks)
 constexpr int kTileBlocks = 10;
 constexpr int kWin = (kTileSub - 1) * 32 + kFbRing + 1;   // 3345 filtered samples
@@ -1534,6 +1537,17 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     // requested further down (request_next) and land in registers while the remaining phases run ----------
     if constexpr (!kOwned)
       if (b0 + kTileBlocks < nb_mine) sh.win.shift(tid);
+    // Which of the next window's new samples a thread brings: sample kKeep + n of thread t's q-th request.  Sample-major
+    // (n = t + 256 q) the 64 lanes of a store walk down a column of the window, rows 112 doubles apart: two bank pairs
+    // for 64 lanes, sixteen-way conflicts on all eight stores of every tile.  FP64 engine: a lane takes column
+    // (lane & 15) + 16 (q & 3) and row (lane >> 4) + 4 wave + 16 (q >> 2) of the 64 x 32 new samples instead -- sixteen
+    // consecutive columns in four consecutive rows per store (two-way), sixteen cache lines per load.
+    auto next_wdx = [&](int q) {
+      if constexpr (sizeof(WT) == 8 && !PEAQ_FB_OLD_NEXT_MAP)
+        return kKeep + 32 * ((lane & 15) + 16 * (q & 3)) + (lane >> 4) + 4 * wv + 16 * (q >> 2);
+      else
+        return kKeep + tid + 256 * q;
+    };
     auto request_next = [&]() {
       if (b0 + kTileBlocks < nb_mine) {
         const size_t first = (size_t)(b0 + kTileBlocks) * kFbFrame;  // row index of the next window's u = 0
@@ -1541,7 +1555,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
         const int avail = (int)min((size_t)kWin, row_valid - first);
 #pragma unroll
         for (int q = 0; q < kPre; ++q) {
-          const int wdx = kKeep + tid + 256 * q;
+          const int wdx = next_wdx(q);
           pre[q] = wdx < avail ? src[wdx] : 0.;
         }
       }
@@ -1779,7 +1793,7 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     if (b0 + kTileBlocks < nb_mine) {
 #pragma unroll
       for (int q = 0; q < kPre; ++q) {
-        const int wdx = kKeep + tid + 256 * q;
+        const int wdx = next_wdx(q);
         if (wdx < kWin) sh.win.put(wdx, pre[q], xs);
       }
     }
