@@ -237,7 +237,12 @@ def device_power_info(index):
                     return float(open(f"{h}/{name}").read().strip()) * scale
                 except Exception:
                     return None
-            info = {"source": h, "power_cap_w": rd("power1_cap", 1e-6), "power_cap_max_w": rd("power1_cap_max", 1e-6),
+            uid = None
+            try:
+                uid = open(h.split("/hwmon/")[0] + "/unique_id").read().strip()   # which board this line was measured on
+            except Exception:
+                pass
+            info = {"source": h, "unique_id": uid, "power_cap_w": rd("power1_cap", 1e-6), "power_cap_max_w": rd("power1_cap_max", 1e-6),
                     "power_now_w": rd("power1_average", 1e-6) or rd("power1_input", 1e-6),
                     "sclk_now_mhz": rd("freq1_input", 1e-6), "temp_c": rd("temp1_input", 1e-3)}
     except Exception:

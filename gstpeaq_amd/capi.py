@@ -32,7 +32,8 @@ class PeaqError(RuntimeError):
 class _Calibration(C.Structure):
     _fields_ = [("elapsed_ms", C.c_double), ("shader_clock_mhz", C.c_double), ("fp64_tflops", C.c_double),
                 ("cycles_per_fma", C.c_double), ("max_clock_mhz", C.c_double), ("compute_units", C.c_int),
-                ("ramp_clock_mhz", C.c_double), ("ramp_cycles_per_fma", C.c_double), ("event_fp64_tflops", C.c_double)]
+                ("ramp_clock_mhz", C.c_double), ("ramp_cycles_per_fma", C.c_double), ("event_fp64_tflops", C.c_double),
+                ("simds_used", C.c_int), ("max_waves_on_a_simd", C.c_int), ("dispatch_spread_ms", C.c_double)]
 
 
 class _Timing(C.Structure):

@@ -282,10 +282,14 @@ __global__ __launch_bounds__(64) void calib_kernel(double* out, unsigned long lo
   for (int k = 0; k < 16; ++k) sum += a[k];
   out[blockIdx.x * 64 + threadIdx.x] = sum;
   if (threadIdx.x == 0) {
-    ticks[4 * blockIdx.x] = cy[1] - cy[0];
-    ticks[4 * blockIdx.x + 1] = w[1] - w[0];
-    ticks[4 * blockIdx.x + 2] = cy[2] - cy[1];
-    ticks[4 * blockIdx.x + 3] = w[2] - w[1];
+    ticks[6 * blockIdx.x] = cy[1] - cy[0];
+    ticks[6 * blockIdx.x + 1] = w[1] - w[0];
+    ticks[6 * blockIdx.x + 2] = cy[2] - cy[1];
+    ticks[6 * blockIdx.x + 3] = w[2] - w[1];
+    // where the wave ran: HW_ID (wave slot, SIMD, CU, shader array and engine) and the XCC; and when it started
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    ticks[6 * blockIdx.x + 4] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+    ticks[6 * blockIdx.x + 5] = w[0];
   }
 }
 constexpr int kCalibFmasPerIter = 512;               // 16 chains x 32 (the loop's own ~ 40 cycles per trip: 2 % of 2048)
@@ -304,7 +308,7 @@ extern "C" int peaq_calibrate(peaq_ctx* c, int iterations, peaq_calibration* out
   const int waves = prop.multiProcessorCount * 4;      // one per SIMD
   TmpBuf sink, ticks;
   HIP_TRY(sink.reserve((size_t)waves * 64 * sizeof(double)));
-  HIP_TRY(ticks.reserve((size_t)waves * 4 * sizeof(unsigned long long)));
+  HIP_TRY(ticks.reserve((size_t)waves * 6 * sizeof(unsigned long long)));
   // "The clock under a fixed load" means NOTHING else on the device: this context's batch, and whatever its sessions,
   // brokers or other contexts of the process still have in flight (their streams do not synchronise with ours).
   // Work of OTHER processes on the device cannot be seen from here: the caller's responsibility (include/peaq_amd.h).
@@ -328,14 +332,32 @@ extern "C" int peaq_calibrate(peaq_ctx* c, int iterations, peaq_calibration* out
   HIP_TRY(hipEventSynchronize(sc.b));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, sc.a, sc.b));
-  std::vector<unsigned long long> h((size_t)waves * 4);
+  std::vector<unsigned long long> h((size_t)waves * 6);
   HIP_TRY(hipMemcpy(h.data(), ticks.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   double shader[2] = {0., 0.}, wall[2] = {0., 0.};
-  for (int i = 0; i < waves; ++i)
+  // the SIMDs the waves ran on (XCC, shader engine / array, CU, SIMD: HW_ID bits 4-5 SIMD, 8-11 CU, 12 array, 13-15
+  // engine) and how many waves the busiest of them got; the spread of the waves' start times
+  std::vector<unsigned long long> simd_key((size_t)waves);
+  unsigned long long t_first = ~0ull, t_last = 0;
+  for (int i = 0; i < waves; ++i) {
     for (int k = 0; k < 2; ++k) {
-      shader[k] += (double)h[4 * i + 2 * k];
-      wall[k] += (double)h[4 * i + 2 * k + 1];
+      shader[k] += (double)h[6 * i + 2 * k];
+      wall[k] += (double)h[6 * i + 2 * k + 1];
     }
+    const unsigned long long id = h[6 * i + 4];
+    simd_key[i] = (id >> 32 << 16) | (id & 0xff30u);
+    t_first = std::min(t_first, h[6 * i + 5]);
+    t_last = std::max(t_last, h[6 * i + 5]);
+  }
+  std::sort(simd_key.begin(), simd_key.end());
+  int distinct = 0, busiest = 0;
+  for (size_t i = 0; i < simd_key.size();) {
+    size_t j = i;
+    while (j < simd_key.size() && simd_key[j] == simd_key[i]) ++j;
+    ++distinct;
+    busiest = std::max(busiest, (int)(j - i));
+    i = j;
+  }
   const double fmas_half = (double)waves * 64. * kCalibFmasPerIter * half;   // lanes x multiply-adds per iteration x iterations
   const double wall_hz = wall_khz * 1e3;
   auto mhz = [&](int k) { return wall[k] > 0. ? shader[k] / wall[k] * (wall_khz * 1e-3) : 0.; };
@@ -350,5 +372,8 @@ extern "C" int peaq_calibrate(peaq_ctx* c, int iterations, peaq_calibration* out
   out->ramp_clock_mhz = mhz(0);
   out->ramp_cycles_per_fma = cpf(0);
   out->event_fp64_tflops = ms > 0.f ? 4. * fmas_half / (ms * 1e-3) * 1e-12 : 0.;
+  out->simds_used = distinct;
+  out->max_waves_on_a_simd = busiest;
+  out->dispatch_spread_ms = (double)(t_last - t_first) / wall_hz * 1e3;
   return PEAQ_OK;
 }

@@ -284,6 +284,13 @@ typedef struct {
   double ramp_clock_mhz;      /* the same over the first half: from the idle clock upwards, waves still being dispatched */
   double ramp_cycles_per_fma;
   double event_fp64_tflops;   /* 2 x all multiply-adds / elapsed_ms: includes launch, ramp and tail */
+  /* where the kernel's waves (one per SIMD of the device as the runtime reports it) actually ran: distinct SIMDs
+   * (HW_ID / XCC_ID of every wave), the most waves any one of them got (2 = that SIMD ran them one after the other:
+   * the kernel then lasts twice a wave's lifetime and event_fp64_tflops halves), and the time between the first and
+   * the last wave's start */
+  int    simds_used;
+  int    max_waves_on_a_simd;
+  double dispatch_spread_ms;
 } peaq_calibration;
 int peaq_calibrate (peaq_ctx *ctx, int iterations, peaq_calibration *out);
 
