@@ -82,3 +82,23 @@ def test_three_waves_per_simd_for_the_fft_path(tmp_path):
         assert v["vgpr_count"] <= 170 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
     v = find(be, "backend_kernelILi109ELb0ELb0E")
     assert v["vgpr_count"] <= 170 and v["vgpr_spill_count"] == 0, v
+
+
+def test_scratch_use_is_where_it_is_known_to_be(tmp_path):
+    """Scratch memory anywhere else than listed here is a regression nobody would otherwise notice (the kernels stay
+    correct, a phase just gets slower).  The hot kernels of the basic version and the FFT path have none; the
+    filter-bank back end keeps ten registers of per-block constants in scratch OUTSIDE its block loop (held to 128
+    registers so that two of its waves fit in the place of one bank wave); finalize_kernel (one thread per
+    pair, once per batch: run-time indexed MOV tables) and synth_kernel (the workload generator, never timed) index small
+    local arrays at run time."""
+    be = kernel_metadata("peaq_backend.hip", tmp_path)
+    for k in ("backend_kernelILi109ELb0ELb0E", "backend_kernelILi55ELb1ELb0E", "state_init_kernel"):
+        v = find(be, k)
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
+    v = find(be, "fb_backend_kernelILb0E")
+    assert v["vgpr_count"] <= 128 and v["private_segment_fixed_size"] <= 64 and v["vgpr_spill_count"] <= 12, v
+    v = find(be, "finalize_kernel")
+    assert v["private_segment_fixed_size"] <= 256 and v["vgpr_spill_count"] == 0, v
+    sy = kernel_metadata("peaq_synth.hip", tmp_path)
+    v = find(sy, "synth_kernel")
+    assert v["private_segment_fixed_size"] <= 256 and v["vgpr_spill_count"] == 0, v
