@@ -406,7 +406,7 @@ enum { MA_RMSMOD, MA_NLASYM, MA_SEGNMR, MA_EHS, MA_LINDIST };   // gstpeaq.c:86-
 
 struct BackendShared {
   double pa[2][2][kPaStride];       // [wave][ref/test][pad + band] pattern-adaptation ratios
-  double pc[2][kLdsBands];          // detection probabilities per channel
+  double pc[2][kLdsBands];          // exponents xb of the detection probabilities 1 - 0.5^xb, per channel
   double qc[2][kLdsBands];
   double acc[2][kAccFields][kAccLdsStride];   // [channel][field][accumulator]
   double energy[2];                 // totalsnr: signal and noise energy so far (lane 0 of channel 0)
@@ -608,7 +608,11 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
           const double e = er_db - et_db;
           const double x = e * inv_sd, x2 = x * x;
           const double xb = er_db > et_db ? x2 * x2 : x2 * x2 * x2;   // (e/s)^b, b = 4 or 6
-          pc = 1. - bt.exp(-kLn2 * xb);                             // 1 - 0.5^((e/s)^b)
+          // The channel's detection probability is pc = 1 - 0.5^xb (movs.c:1253); what the frame needs of it is
+          // prod_b (1 - max_c pc) = 0.5^(sum_b max_c xb) (pc grows with xb, so the maxima agree): the EXPONENTS are
+          // exchanged and summed, and the one exponential of the frame is taken after the reduction -- an exponential
+          // per band, channel and frame less, and the product's own reduction rides in the free slot of the sums'.
+          pc = xb;
           qc = fabs(a.cfg.floor_steps ? floor(e) : trunc(e)) * inv_sd;        // movs.c:1256-1260
         }
         sh.pc[chan][bl.band(s)] = pc;
@@ -664,26 +668,25 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
           if (r > nmax) nmax = r;
         }
       }
-      double pprod = 1., qsum = 0.;
+      double xsum = 0., qsum = 0.;                    // sum of the bands' exponents (pc above), of the steps
       if (!ADV && chan == 0) {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
           if (bl.valid(s)) {
             const int b = bl.band(s);
-            double p = 0., q = sh.qc[0][b];
-            if (sh.pc[0][b] > p) p = sh.pc[0][b];
+            double x = fmax(sh.pc[0][b], 0.), q = sh.qc[0][b];      // (fmax: a NaN exponent counts as 0, like `pc > p`)
             if (channels == 2) {
-              if (sh.pc[1][b] > p) p = sh.pc[1][b];
+              if (sh.pc[1][b] > x) x = sh.pc[1][b];
               if (sh.qc[1][b] > q) q = sh.qc[1][b];
             }
-            pprod *= 1. - p;
+            xsum += x;
             qsum += q;
           }
         }
       }
-      double nl_sum, none;
+      double nl_sum;
       if (!ADV)
-        wave_sum4(nsum, nl_part, qsum, 0., nsum, nl_sum, qsum, none);
+        wave_sum4(nsum, nl_part, qsum, xsum, nsum, nl_sum, qsum, xsum);
       else
         nsum = wave_sum(nsum);
       nsum /= NB;
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(128, 3) void backend_kernel(BackendArgs a) {
           a.debug[((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels + chan) * kDbgDoubles + kDbgMov + 3] = seg;
       }
       if (!ADV && chan == 0) {
-        const double p_bin = 1. - wave_prod(pprod);
+        const double p_bin = 1. - bt.exp(-kLn2 * xsum);             // 1 - prod_b 0.5^xb (movs.c:1263-1270)
         if (DBG && lane == 0) {
           double* __restrict__ d =
               a.debug + ((size_t)(pair * a.frames_per_launch + (frame - f_begin)) * channels) * kDbgDoubles + kDbgMov;
