@@ -1228,17 +1228,17 @@ __device__ __forceinline__ void spread_up_owned(const double (*are)[kACols], con
       if (j0 < kFbBands) {
         const int r = j0 - b;
         const double c = c1[buf][k], c2 = c * c, c4 = c2 * c2;
-        const double cr = r == 1 ? c : r == 2 ? c2 : r == 3 ? c2 * c : c4;
-        double pr = sr[buf][k] * cr, pi = si[buf][k] * cr;
+        // (the POWER walks on, not the two products as in the reference's loop, fbearmodel.c:343-348: one multiply and
+        // two multiply-adds per (source, target) pair instead of two multiplies and two additions; the same sums in
+        // another association -- last bits, like the rest of this function's order)
+        double pw = r == 1 ? c : r == 2 ? c2 : r == 3 ? c2 * c : c4;
+        const double ar = sr[buf][k], ai = si[buf][k];
 #pragma unroll
         for (int j = j0; j < kFbBands; j += 4) {
           const int n = (j - (W == 0 ? 4 : W)) / 4;               // slot of target j among the wave's targets
-          acr[n] += pr;
-          aci[n] += pi;
-          if (j + 4 < kFbBands) {
-            pr *= c4;
-            pi *= c4;
-          }
+          acr[n] = fma(pw, ar, acr[n]);
+          aci[n] = fma(pw, ai, aci[n]);
+          if (j + 4 < kFbBands) pw *= c4;
         }
       }
     }
