@@ -364,6 +364,16 @@ void frontend_kernel(FrontendArgs a) {
   // a fresh wave gets its frame requested before its older neighbours on the SIMD issue their next arithmetic:
   // what it waits for longest is that frame (+ 0.5 % measured; back to normal once the loads are out)
   __builtin_amdgcn_s_setprio(3);
+#ifndef PEAQ_FE_LAZY_KERNARGS
+  // Everything the start-up needs of the argument block is "used" HERE: the compiler then issues the scalar loads
+  // together and waits once.  Left to itself it fetches the block piece by piece where the pieces are first needed --
+  // five dependent round trips through the scalar cache (~ 1.4 k cycles between a wave's first instruction and its
+  // first sample load, profiles/r06_frontend_phases.json phases 15 + 13).
+  asm volatile("" ::"s"(a.ref), "s"(a.test), "s"(a.pair_stride), "s"(a.n_ref), "s"(a.n_test), "s"(a.n_uniform_ref),
+               "s"(a.n_uniform_test), "s"(a.n_frames), "s"(a.n_frames_uniform), "s"(a.frame_origin), "s"(a.off_ref),
+               "s"(a.off_test), "s"(a.channels), "s"(a.frame0), "s"(a.frames_per_launch), "s"(a.fpl_magic), "s"(a.common),
+               "s"(a.records), "s"(a.pair_frame0), "s"(gridDim.x));
+#endif
   const int lane = threadIdx.x & 63;
   // 0 = reference wave, 1 = test wave; wave-uniform, so keep it (and all that hangs on it) scalar
   const int sig = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
