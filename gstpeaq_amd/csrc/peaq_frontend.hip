@@ -780,13 +780,18 @@ void frontend_kernel(FrontendArgs a) {
   }
 
   // ---- error harmonic structure, part 1 (movs.c:1383-1391): d[k] = ln(Pw_test / Pw_ref), k < 512.
-  // The test wave takes 6 of the 8 values per lane: its tail (noise spectrum) is the shorter one.
+  // The test wave takes 5 of the 8 values per lane: its tail (noise spectrum) is the shorter one, but with 6 the
+  // reference wave stood 1.3 k cycles at the barrier behind this loop.
   if constexpr (!kAdvanced) {
     double* dlog = sa;
+#ifndef PEAQ_FE_RATIOS_REF
+#define PEAQ_FE_RATIOS_REF 3                         // (2 / 3 / 4 / 1 of the 8: 28.81 / 28.95 / 28.90 / 28.69 M, profiles/r06_ab_basic.txt)
+#endif
+    constexpr int kRefRatios = PEAQ_FE_RATIOS_REF;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      if (sig == 0 && j >= 2) break;
-      const int k = (sig == 0 ? 0 : 128) + lane + 64 * j;
+    for (int j = 0; j < 8 - kRefRatios; ++j) {
+      if (sig == 0 && j >= kRefRatios) break;
+      const int k = (sig == 0 ? 0 : 64 * kRefRatios) + lane + 64 * j;
       const double fr = pw_ref[k], ft = pw_test[k];
       dlog[k] = (fr == 0. && ft == 0.) ? 0. : FE_LOG_NONNEG(ft / fr, ltab);   // +-inf when one side is digital silence
     }
