@@ -1697,7 +1697,14 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
       }
     }
     __syncthreads();
-    if constexpr (sizeof(WT) == 8) request_next();
+    if constexpr (sizeof(WT) == 8) {
+      request_next();
+      // ... and the next tile's copy of the logarithm table (see phase 0): asked for HERE and waited for in front of
+      // the records' stores below.  Asked for behind phase 5 and first touched at the next tile's top, the wait there
+      // was `vmcnt(0)` -- the compiler cannot count the stores of the records' loop -- i.e. a wait for the
+      // acknowledgement of this tile's stores from HBM: 2.2 k cycles at the top of every tile.
+      if (b0 + kTileBlocks < nb_mine) request_ltab();
+    }
     FB_MARK(8);
     // ---- phase 4: rectification + backward masking at block rate (fbearmodel.c:357-382), wave-local: a
     // wave takes the ten bands it carried through phase 2, first E0 = re^2 + im^2 for all time points (lane =
@@ -1776,7 +1783,10 @@ __device__ __forceinline__ void fb_bank_body(const FbFrontArgs& a, unsigned n_si
     }
     __syncthreads();
     FB_MARK(11);
-    if (b0 + kTileBlocks < nb_mine) request_ltab();  // the next tile's copy of the logarithm table (see phase 0)
+    if constexpr (sizeof(WT) == 8)                   // (the table's entries have arrived: nothing the next tile's top
+      asm volatile("" : "+v"(ltab_in[0]), "+v"(ltab_in[1]));   // needs is in flight behind the stores below)
+    else if (b0 + kTileBlocks < nb_mine)
+      request_ltab();
     for (int item = tid; item < kFbBands * (int)nvb; item += 256) {
       const int bl = item / kFbBands, b = item - bl * kFbBands;      // 40 consecutive doubles per block
       double* rec = a.records + ((size_t)(pair * a.blocks_per_launch + b0 + bl) * a.channels + chan) * kFbRecDoubles;
