@@ -143,3 +143,34 @@ def test_two_runs_agree_bit_for_bit(advanced):
     assert not np.isnan(runs[0][:, 12]).any()
     for r in runs[1:]:
         assert np.array_equal(runs[0].view(np.uint64), r.view(np.uint64))
+
+
+@pytest.mark.parametrize("advanced", [0, 1], ids=["basic", "advanced"])
+def test_256_seeded_pairs_against_the_real_reference_element(advanced):
+    """SURVEY.md 8(d)'s parity subset as a test: the first 256 pairs of the bench workload (10 s stereo, seeds 1 .. 256)
+    through the HIP path and through the reference element itself (`oracle/_ref/ref_harness`, built from the
+    reference's sources in the build container and carried along; one process per host core) -- not the oracle.
+    tools/parity_soak.py does the same for all 4096 (profiles/r06_parity_soak.json)."""
+    import sys
+    from pathlib import Path
+    import torch
+    import gstpeaq_amd
+    root = Path(__file__).resolve().parent.parent
+    if not (root / "oracle" / "_ref" / "ref_harness").exists():
+        pytest.skip("oracle/_ref/ref_harness was not built (needs /root/reference at build time)")
+    sys.path.insert(0, str(root))
+    import bench
+    n, ns = 256, 480000
+    ctx = gstpeaq_amd.Context(0)
+    ref, test = gstpeaq_amd.synth_fill(ctx, 1, n, 2, ns)
+    res = torch.empty((n, 16), dtype=torch.float64, device=ref.device)
+    gstpeaq_amd.batch_run(ctx, advanced, ref, test, results=res, sync=True)
+    cpu = bench.cpu_records(ns, 2, 1, bool(advanced), n)
+    assert cpu["kind"] == "reference"
+    d = bench.result_deltas(res.cpu().numpy(), cpu, bool(advanced))
+    assert d["delta_pairs"] == n and d["delta_nan_mismatches"] == 0, d
+    assert d["odg_max_abs_delta"] < 1e-7 and d["di_max_abs_delta"] < 1e-7, d
+    assert all(v == 0 for v in d["gated_movs_pairs_differing"].values()), d
+    worst = max(v for v in d["mov_max_rel_delta"].values() if v is not None)
+    assert worst < 1e-6, d                            # (EHS, the loosest: its own cancellation, ~ 1e-8 .. 1e-7)
+    print(f"advanced={advanced}: max |dODG| {d['odg_max_abs_delta']:.2e}, worst MOV {worst:.2e}")
