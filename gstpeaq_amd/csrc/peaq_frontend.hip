@@ -604,14 +604,25 @@ void frontend_kernel(FrontendArgs a) {
   double* pw_test = lds + kUnitDoubles + kOffPw;
   double* sa = lds + kOffScratch;                            // [512] the reference unit's scratch
   double* sb = lds + kUnitDoubles + kOffScratch;             // [512] the test unit's scratch
+  // Advanced version (55 bands): of the test signal only the weighted spectrum is used -- noise in bands and EHS,
+  // process_fft_block_advanced gstpeaq.c:924-959 -- so its wave has no band phase of its own.  The waves meet ONCE, here,
+  // with both weighted spectra in LDS; from there on two one-way flags in LDS replace the barrier (round 6: behind a
+  // second barrier the reference wave ran the whole error-harmonic structure alone, 8.7 k cycles in which the test wave's
+  // slot stood empty -- a fifth of the workgroup's life):
+  //   test wave:  log ratios (into ITS scratch area) -> noise spectrum in place -> flag 1 -> waits for flag 0 -> the
+  //               error-harmonic structure, exchanging through its scratch area and the REFERENCE wave's spectrum
+  //               (dead once that wave has its band sums: flag 0);
+  //   ref wave:   band sums -> flag 0 -> spreading, record -> waits for flag 1 -> the noise spectrum's band sums.
+  int* adv_flag = reinterpret_cast<int*>(lds + kOffLogTab + kLogTabDoubles + 2 * kLogTabEntries);   // the second table's spare words
+  auto wait_flag = [&](int i) {
+    while (__builtin_amdgcn_readfirstlane(*(volatile int*)(adv_flag + i)) == 0) __builtin_amdgcn_s_sleep(1);
+    wave_lds_fence();
+  };
   if constexpr (kAdvanced) {
-    // Advanced version: of the test signal only the weighted spectrum is used -- noise in bands and EHS,
-    // process_fft_block_advanced gstpeaq.c:924-959 -- so its wave has no band phase of its own.  It used to wait at the
-    // barrier behind the reference wave's (a quarter of its lifetime, tools/fe_profile.py) and do its share afterwards;
-    // now the waves meet HERE, with both weighted spectra in LDS, and the test wave does everything that needs both
-    // while the reference wave groups and spreads: all log ratios of the error-harmonic structure (into ITS scratch
-    // area: the reference wave's holds the band sums), then the noise spectrum in place and its band sums.  The
-    // reference wave reads none of what it writes before the second barrier.
+    if (sig == 0 && lane == 0) {
+      adv_flag[0] = 0;
+      adv_flag[1] = 0;
+    }
     __syncthreads();
     if (sig == 1) {
 #pragma unroll
@@ -635,22 +646,10 @@ void frontend_kernel(FrontendArgs a) {
 #pragma unroll
         for (int i = 0; i < kSteps; ++i)
           if (lane + 64 * i < kPwLen) pw_test[lane + 64 * i] = r[i] - 2 * sqrt_pos(r[i] * t[i]) + t[i];
-        if (lane == 0) xch[0] = 0.;                  // the band sums' zero slot (no bandwidth exchange in this version)
       }
       wave_lds_fence();
-      const int zero_at = (int)(xch - pw_test);
-      if (lane < (NB + 1) / 2) {
-        const int b1 = lane, b2 = NB - 1 - lane;
-        rec[kRecNoise + b1] = group_band(edge1, pw_test, zero_at);
-        if (b2 != b1) rec[kRecNoise + b2] = group_band(edge2, pw_test, zero_at);
-      } else if (lane < (NB + 1) / 2 + kBandStride - NB) {
-        rec[kRecNoise + NB + lane - (NB + 1) / 2] = 0.;  // padding slots of the band vector
-      }
-      if (lane == 0) {
-        rec[kRecBwRef] = 0.;
-        rec[kRecBwTest] = 0.;
-      }
-      FE_MARK(10);                                   // test wave: noise spectrum + grouping
+      if (lane == 0) adv_flag[1] = 1;                // the noise spectrum stands (LDS operations of a wave execute in order)
+      FE_MARK(10);                                   // test wave: noise spectrum
     }
   }
   // ---- critical bands, internal noise, spreading ------------------------------------
@@ -680,6 +679,7 @@ void frontend_kernel(FrontendArgs a) {
       if (b2 != b1) ppx[b2] = group_band(edge2, pw, kZeroSlot);
     }
     wave_lds_fence();
+    if (kAdvanced && lane == 0) adv_flag[0] = 1;       // this wave has read its weighted spectrum for the last time
     FE_MARK(3);                                        // band grouping
     // Upward spreading, Kabal (27): E2[j] += Ene[i] a_i^(j-i) for j > i, a_i = aUCEe[i] -- the reference's O(B^2) loop
     // (fftearmodel.c:657-667).  Every band's contributions are a geometric sequence along the target bands; they used
@@ -768,15 +768,35 @@ void frontend_kernel(FrontendArgs a) {
 
   }
   FE_MARK(6);                                        // downward spreading, excitation, record
-  __syncthreads();                                   // both spectra are in LDS (and the test wave's threshold)
-  FE_MARK(7);                                        // barrier
-  if (!kAdvanced && sig == 0) {
-    bw_ref = top_bin(10. * xch[0], 921, false);
-    if (lane == 0) xch[1] = (double)bw_ref;          // read by the test wave behind the next barrier
-  }
-  if (kAdvanced && sig == 1) {                       // advanced version: the test wave is through (the log ratios are in sb)
-    if (pf_keep == 123456.789f) rec[kRecScalars + 15] = 1.;   // (keeps its prefetch alive, see the kernel's last line)
-    return;
+  if constexpr (kAdvanced) {
+    if (sig == 0) {
+      // the band sums of the noise spectrum (movs.c:997-1000), which the test wave has left in its unit
+      const BandEdge e1 = load_band_edge(bt, gb1), e2 = load_band_edge(bt, gb2);   // (asked for again, not held since the transform)
+      if (lane == 0) xch[0] = 0.;                    // the band sums' zero slot (no bandwidth exchange in this version)
+      wait_flag(1);
+      const int zero_at = (int)(xch - pw_test);
+      if (lane < (NB + 1) / 2) {
+        const int b1 = lane, b2 = NB - 1 - lane;
+        rec[kRecNoise + b1] = group_band(e1, pw_test, zero_at);
+        if (b2 != b1) rec[kRecNoise + b2] = group_band(e2, pw_test, zero_at);
+      } else if (lane < (NB + 1) / 2 + kBandStride - NB) {
+        rec[kRecNoise + NB + lane - (NB + 1) / 2] = 0.;  // padding slots of the band vector
+      }
+      if (lane == 0) {
+        rec[kRecBwRef] = 0.;
+        rec[kRecBwTest] = 0.;
+      }
+    } else {
+      wait_flag(0);                                  // the reference wave's spectrum is free: half of the EHS's exchange space
+    }
+    FE_MARK(7);
+  } else {
+    __syncthreads();                                 // both spectra are in LDS (and the test wave's threshold)
+    FE_MARK(7);                                      // barrier
+    if (sig == 0) {
+      bw_ref = top_bin(10. * xch[0], 921, false);
+      if (lane == 0) xch[1] = (double)bw_ref;        // read by the test wave behind the next barrier
+    }
   }
 
   // ---- error harmonic structure, part 1 (movs.c:1383-1391): d[k] = ln(Pw_test / Pw_ref), k < 512.
@@ -806,7 +826,7 @@ void frontend_kernel(FrontendArgs a) {
     if (bw_ref > 346) bw_test = top_bin(3.16227766016838 * thr, bw_ref, true);
   }
 
-  if (sig == 1) {
+  if (!kAdvanced && sig == 1) {
     // ---- noise spectrum for the NMR MOVs (movs.c:992-996): one bin per lane and step, in place
     // over this unit's weighted spectrum (nobody reads it any more); then the band grouping ------
     wave_lds_fence();
@@ -838,7 +858,10 @@ void frontend_kernel(FrontendArgs a) {
       rec[kRecBwTest] = (double)bw_test;
     }
     FE_MARK(10);                                     // test wave: noise spectrum + grouping
-  } else {
+  } else if (kAdvanced ? sig == 1 : sig == 0) {
+    // (basic version: the reference wave; advanced version: the test wave, whose exchange buffers are its own scratch
+    // area and the reference unit's spectrum)
+    double* const sa = kAdvanced ? lds + kOffPw : lds + kOffScratch;
     // ---- error harmonic structure, part 2: c[l] = sum_{k<256} d[k] d[k+l], l < 256, the way the
     // reference does it (movs.c:1279-1315): with A = DFT_512(d[0..255], zero padded) and
     // B = DFT_512(d[0..511]) the sums are the inverse DFT of B conj(A).  Both transforms of real data
